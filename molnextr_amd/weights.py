@@ -311,11 +311,16 @@ def _shape_decode_dynamics(d: "OrderedDict[str, torch.Tensor]", dec: DecoderDims
     d[L0 + "final_linear.weight"][6, 0] = 1.0
 
 
+def synthetic_encoder_state(seed: int = 0, enc: EncoderDims = SWIN_B) -> "OrderedDict[str, torch.Tensor]":
+    """Only the encoder half of `synthetic_checkpoint` (used with small test configurations)."""
+    return OrderedDict((k, _synth_tensor(k, shp, seed, enc.window)) for k, shp in encoder_spec(enc).items())
+
+
 def synthetic_checkpoint(seed: int = 0, enc: EncoderDims = SWIN_B, dec: DecoderDims = DEC,
                          molecule_like: bool = True) -> dict:
     """A checkpoint dict with the reference's layout: {'encoder': sd, 'decoder': sd, 'args': {...}}
     (reference main.py:389-398). Deterministic in (seed, dims)."""
-    e = OrderedDict((k, _synth_tensor(k, shp, seed, enc.window)) for k, shp in encoder_spec(enc).items())
+    e = synthetic_encoder_state(seed, enc)
     d = OrderedDict((k, _synth_tensor(k, shp, seed, enc.window)) for k, shp in decoder_spec(dec).items())
     if molecule_like:
         _shape_decode_dynamics(d, dec)

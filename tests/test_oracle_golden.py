@@ -1,0 +1,119 @@
+"""CPU: the oracle (oracle/) against the golden vectors generated from the reference itself
+(tools/gen_golden.py, run in the build container). This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from molnextr_amd import weights as W
+from oracle import SwinConfig
+from oracle.decoder import greedy_decode, grammar_mask, sinusoid_pe
+from oracle.edges import edge_logits, predict_edges, symmetrise
+from oracle.swin import encoder_forward, relative_position_index
+
+TINY_W = W.EncoderDims(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)
+TINY_O = SwinConfig(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)
+P = "decoder.chartok_coords."
+
+
+def test_swin_tiny_every_block(golden_dir):
+    g = np.load(os.path.join(golden_dir, "swin_tiny.npz"))
+    sd = W.synthetic_encoder_state(0, TINY_W)
+    img = W.hash_normal("swin_tiny_img", (2, 3, 96, 96), 1.0)
+    taps = {}
+    feats = encoder_forward(img, sd, TINY_O, tap=lambda n, t: taps.__setitem__(n, t.clone()))
+    for name in ("patch_embed", "s0b0", "s0b1", "merge0", "s1b0", "s1b1"):
+        np.testing.assert_allclose(taps[name].numpy(), g[name], rtol=0, atol=2e-5, err_msg=name)
+    np.testing.assert_allclose(feats.numpy(), g["features"], rtol=0, atol=2e-5)
+
+
+def test_swin_full_384(golden_dir, synth_ckpt):
+    g = np.load(os.path.join(golden_dir, "swin_full.npz"))
+    img = W.synthetic_images(2)
+    f, hid = encoder_forward(img, synth_ckpt["encoder"], return_hiddens=True)
+    f = f.numpy()
+    assert f.shape == (2, 144, 1024)
+    np.testing.assert_allclose(f[:, :4, :], g["features_head"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(f[:, ::9, ::16], g["features_strided"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(np.abs(f).sum(axis=(1, 2)), g["features_abs_sum"], rtol=1e-5)
+    np.testing.assert_allclose(hid[0].numpy()[:, ::512, ::8], g["hidden0_strided"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(hid[2].numpy()[:, ::36, ::32], g["hidden2_strided"], atol=1e-4, rtol=0)
+
+
+def test_relative_position_index_matches_contract():
+    assert torch.equal(relative_position_index(12), W.relative_position_index(12))
+    idx = relative_position_index(12)
+    assert idx[0, 0] == 11 * 23 + 11 and idx[0, 143] == 0 and idx[143, 0] == 528
+
+
+def _check_greedy(g, res, max_len):
+    B = g["ids"].shape[0]
+    for b in range(B):
+        n = int(g["lens"][b])
+        assert res.tokens[b] == g["ids"][b, :n].tolist(), f"row {b} token ids differ"
+        np.testing.assert_allclose(np.array(res.token_logp[b], dtype=np.float32), g["token_logp"][b, :n], atol=2e-4)
+        np.testing.assert_allclose(res.hidden[b][:8].numpy(), g["hidden_head"][b, :min(8, n)], atol=2e-5)
+        np.testing.assert_allclose(res.hidden[b].double().sum(0).numpy(), g["hidden_sum"][b], atol=2e-3)
+    np.testing.assert_allclose(np.array(res.scores), g["scores"], rtol=1e-4)
+
+
+def test_decoder_greedy_with_compaction(golden_dir, synth_ckpt):
+    """B=6, rows finish at different steps: exercises the batch-row positional-encoding quirk under compaction."""
+    g = np.load(os.path.join(golden_dir, "decoder_greedy.npz"))
+    feats = W.hash_normal("decoder_greedy_features", (6, 144, 1024), 0.5)
+    res = greedy_decode(feats, synth_ckpt["decoder"], trace=True)
+    assert len(set(g["lens"].tolist())) > 3, "fixture must contain rows of different length"
+    _check_greedy(g, res, 480)
+    for s in range(4):
+        alive, logits = res.logits_trace[s]
+        np.testing.assert_allclose(logits.numpy(), g[f"logits_step{s}"], atol=5e-5)
+
+
+def test_decoder_max_length_finish(golden_dir, synth_ckpt):
+    g = np.load(os.path.join(golden_dir, "decoder_short.npz"))
+    feats = W.hash_normal("decoder_short_features", (3, 144, 1024), 0.5)
+    res = greedy_decode(feats, synth_ckpt["decoder"], max_len=24)
+    _check_greedy(g, res, 24)
+    assert all(len(t) == 24 for t in res.tokens)
+
+
+def test_embedding_row_indexed_pe(golden_dir, synth_ckpt):
+    """emb[b] = W[tok_b] * 16 + pe[b]  — PE indexed by batch row (reference components.py:290, embedding.py:52-59)."""
+    g = np.load(os.path.join(golden_dir, "embedding_pe.npz"))
+    sd = synth_ckpt["decoder"]
+    emb_w = sd[P + "embeddings.make_embedding.emb_luts.0.weight"]
+    pe = sd[P + "embeddings.make_embedding.pe.pe"].reshape(-1, 256)
+    ids = torch.from_numpy(g["ids"]).long()
+    mine = emb_w[ids] * 16.0 + pe[: len(ids)]
+    np.testing.assert_allclose(mine.numpy(), g["emb"], atol=1e-6)
+    np.testing.assert_allclose(sinusoid_pe(5000, 256).numpy(), pe.numpy(), atol=0)
+
+
+def test_grammar_mask_truth_table(golden_dir):
+    with open(os.path.join(golden_dir, "tokenizer.json")) as f:
+        t = json.load(f)
+    m = grammar_mask(torch.arange(229))
+    for i, row in enumerate(t["masks"]):
+        assert "".join("1" if v else "0" for v in m[i].tolist()) == row, f"prev id {i}"
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_edge_head(golden_dir, synth_ckpt, name):
+    g = np.load(os.path.join(golden_dir, "edges.npz"))
+    T = {"a": 40, "b": 90, "c": 12, "d": 20}[name]
+    hidden = W.hash_normal(f"edges_hidden_{name}", (T, 256), 1.0)
+    idx = g[f"{name}_idx"]
+    np.testing.assert_allclose(edge_logits(hidden, idx, synth_ckpt["decoder"]).numpy(), g[f"{name}_logits"], atol=2e-5)
+    e, s = predict_edges(hidden, idx, synth_ckpt["decoder"])
+    assert np.array_equal(e, g[f"{name}_edges"])
+    np.testing.assert_allclose(s, g[f"{name}_scores"], atol=1e-6)
+
+
+def test_edge_symmetrise_raw(golden_dir):
+    g = np.load(os.path.join(golden_dir, "edges.npz"))
+    e = symmetrise(g["raw_prob"])
+    assert np.array_equal(np.argmax(e, axis=2), g["raw_edges"])
+    np.testing.assert_allclose(np.max(e, axis=2), g["raw_scores"], atol=0)
+    assert np.array_equal(symmetrise(np.zeros((0, 0, 7))), np.zeros((0, 0, 7)))

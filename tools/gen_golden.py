@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Container-only: imports the reference's own hot-path files from /root/reference (read-only) through
+tools/ref_import.py and runs them on deterministic inputs (hash-generated weights and tensors from
+molnextr_amd.weights — no torch RNG, so the GPU box regenerates the same inputs without the reference).
+Only inputs-by-recipe and expected OUTPUTS are stored; no reference source travels.
+
+    python tools/gen_golden.py            # rewrites tests/golden/*.npz, *.json
+
+Fixtures (all small):
+  swin_tiny.npz        tiny Vision_Transformer (img 96, C 32, depths 2/2, heads 1/2, window 12): every block output
+  swin_full.npz        swin_base @384 on 2 synthetic images under synthetic_checkpoint(0): feature slices + moments
+  decoder_greedy.npz   TransformerDecoderAR.decode (greedy, max_length 480) on hash features, B=6: ids, log-probs,
+                       finish steps, hidden slices, first-steps logits   (covers the batch-row PE quirk + compaction)
+  decoder_short.npz    same with max_length 24 on B=3 (max-length finish path)
+  embedding_pe.npz     Embeddings.forward on [B,1,1] ids: the row-indexed positional encoding
+  edges.npz            GraphPredictor + softmax + get_edge_prediction on hash hidden states
+  tokenizer.json       get_output_mask truth table (229 ids) + sequence_to_smiles cases
+  predict_e2e.json     Decoder.decode end-to-end on B=4: smiles / symbols / coords / indices / edges
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from ref_import import have_reference, import_reference, reference_args  # noqa: E402
+from molnextr_amd import weights as W  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TINY = W.EncoderDims(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()[:16]
+
+
+def gen_swin_tiny(VT):
+    sd = W.synthetic_encoder_state(0, TINY)
+    model = VT(img_size=96, patch_size=4, embed_dim=32, depths=(2, 2), num_heads=(1, 2), window_size=12,
+               num_classes=0).eval()
+    strict = {k[len("transformer."):]: v for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(strict, strict=False)
+    assert not unexpected and all(m.startswith("head") for m in missing), (missing, unexpected)
+    img = W.hash_normal("swin_tiny_img", (2, 3, 96, 96), 1.0)
+    taps = {}
+    hooks = []
+    for si, layer in enumerate(model.layers):
+        for bi, blk in enumerate(layer.blocks):
+            hooks.append(blk.register_forward_hook(
+                lambda m, i, o, name=f"s{si}b{bi}": taps.__setitem__(name, o.detach().clone())))
+        if layer.downsample is not None:
+            hooks.append(layer.downsample.register_forward_hook(
+                lambda m, i, o, name=f"merge{si}": taps.__setitem__(name, o[0].detach().clone())))
+    hooks.append(model.patch_embed.register_forward_hook(
+        lambda m, i, o: taps.__setitem__("patch_embed", o[0].detach().clone())))
+    with torch.no_grad():
+        feats, hiddens = model(img)
+    for h in hooks:
+        h.remove()
+    out = {k: v.numpy() for k, v in taps.items()}
+    out["features"] = feats.numpy()
+    np.savez_compressed(os.path.join(GOLD, "swin_tiny.npz"), **out)
+    print("swin_tiny:", {k: v.shape for k, v in out.items()})
+
+
+def gen_swin_full(Encoder, args, ck):
+    enc = Encoder(args).eval()
+    enc.load_state_dict(ck["encoder"], strict=True)
+    img = W.synthetic_images(2)
+    with torch.no_grad():
+        f, hiddens = enc(img)
+    f = f.numpy()
+    out = {
+        "features_head": f[:, :4, :].copy(),                 # first 4 tokens, all channels
+        "features_strided": f[:, ::9, ::16].copy(),          # 16 tokens x 64 channels
+        "features_mean": f.mean(axis=(1, 2)), "features_std": f.std(axis=(1, 2)),
+        "features_abs_sum": np.abs(f).sum(axis=(1, 2)),
+        "hidden0_strided": hiddens[0].numpy()[:, ::512, ::8].copy(),
+        "hidden2_strided": hiddens[2].numpy()[:, ::36, ::32].copy(),
+    }
+    np.savez_compressed(os.path.join(GOLD, "swin_full.npz"), **out)
+    print("swin_full: features", f.shape, "rms", float(np.sqrt((f ** 2).mean())))
+    return torch.from_numpy(f)
+
+
+def run_greedy(dec, feats, max_length, n_logit_steps=4):
+    ar = dec.decoder["chartok_coords"]
+    logits = []
+    h = ar.output_layer.register_forward_hook(lambda m, i, o: logits.append(o.detach().clone()))
+    with torch.no_grad():
+        preds, scores, token_scores, hidden = ar.decode(feats, 1, 1, max_length=max_length)
+    h.remove()
+    B = feats.shape[0]
+    ids = np.full((B, max_length), -1, dtype=np.int32)
+    logp = np.zeros((B, max_length), dtype=np.float32)
+    lens = np.zeros(B, dtype=np.int32)
+    hid_head = np.zeros((B, 8, 256), dtype=np.float32)
+    hid_sum = np.zeros((B, 256), dtype=np.float64)
+    for b in range(B):
+        t = preds[b][0].numpy()
+        lens[b] = len(t)
+        ids[b, :len(t)] = t
+        logp[b, :len(t)] = np.log(np.array(token_scores[b][0], dtype=np.float64)).astype(np.float32)
+        hb = hidden[b][0].numpy()
+        hid_head[b, :min(8, len(t))] = hb[:8]
+        hid_sum[b] = hb.astype(np.float64).sum(0)
+    out = {"ids": ids, "lens": lens, "token_logp": logp, "scores": np.array([s[0] for s in scores], dtype=np.float64),
+           "hidden_head": hid_head, "hidden_sum": hid_sum}
+    for s in range(min(n_logit_steps, len(logits))):
+        out[f"logits_step{s}"] = logits[s].squeeze(1).numpy()
+    return out, preds, hidden
+
+
+def gen_decoder(Decoder, args, tok, ck):
+    dec = Decoder(args, tok).eval()
+    dec.load_state_dict(ck["decoder"], strict=True)
+    feats = W.hash_normal("decoder_greedy_features", (6, 144, 1024), 0.5)
+    out, _, _ = run_greedy(dec, feats, 480)
+    np.savez_compressed(os.path.join(GOLD, "decoder_greedy.npz"), **out)
+    print("decoder_greedy: lens", out["lens"].tolist())
+    feats3 = W.hash_normal("decoder_short_features", (3, 144, 1024), 0.5)
+    out3, _, _ = run_greedy(dec, feats3, 24)
+    np.savez_compressed(os.path.join(GOLD, "decoder_short.npz"), **out3)
+    print("decoder_short: lens", out3["lens"].tolist())
+    # row-indexed PE
+    ar = dec.decoder["chartok_coords"]
+    ids = torch.tensor([1, 57, 130, 200, 2, 57, 57]).view(-1, 1, 1)
+    with torch.no_grad():
+        emb, _ = ar.dec_embedding(ids)
+    np.savez_compressed(os.path.join(GOLD, "embedding_pe.npz"), ids=ids.view(-1).numpy().astype(np.int32),
+                        emb=emb.squeeze(1).numpy())
+    return dec
+
+
+def gen_edges(dec, get_edge_prediction):
+    gp = dec.decoder["edges"]
+    cases = {}
+    for name, T, k in (("a", 40, 9), ("b", 90, 30), ("c", 12, 1), ("d", 20, 2)):
+        hidden = W.hash_normal(f"edges_hidden_{name}", (T, 256), 1.0)
+        u = W.hash_uniform(f"edges_idx_{name}", k)
+        idx = np.sort((u * T).astype(np.int64))
+        with torch.no_grad():
+            pred = gp(hidden.unsqueeze(0), torch.from_numpy(idx).unsqueeze(0))
+            prob = torch.softmax(pred["edges"].squeeze(0).permute(1, 2, 0), dim=2)
+        e, s = get_edge_prediction(prob.tolist())
+        cases[f"{name}_idx"] = idx.astype(np.int32)
+        cases[f"{name}_logits"] = pred["edges"].squeeze(0).permute(1, 2, 0).numpy()
+        cases[f"{name}_edges"] = np.array(e, dtype=np.int32).reshape(k, k)
+        cases[f"{name}_scores"] = np.array(s, dtype=np.float64).reshape(k, k)
+    # symmetrisation on raw (non-normalised) tables
+    p = W.hash_uniform("edge_prob_raw", 7 * 7 * 7).reshape(7, 7, 7)
+    e, s = get_edge_prediction(p.tolist())
+    cases["raw_prob"] = p
+    cases["raw_edges"] = np.array(e, dtype=np.int32)
+    cases["raw_scores"] = np.array(s, dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "edges.npz"), **cases)
+    print("edges: cases a,b,c,d,raw")
+
+
+def gen_tokenizer(tok, decoded_ids):
+    t = tok["chartok_coords"]
+    masks = ["".join("1" if m else "0" for m in t.get_output_mask(i)) for i in range(len(t))]
+    # run-length: store per id the (first_forbidden, last_forbidden+1) since masks are one contiguous run or empty
+    cases = []
+    s = t.stoi
+    hand = [
+        [],
+        [2],
+        [s["C"], 110, 180, 2],
+        [s["C"], 110, 180, s["C"], 111, 181, 2],
+        [s["C"], s["l"], 120, 190, s["B"], s["r"], 121, 191, s["O"], 2],
+        [s["["], s["C"], s["@"], s["H"], s["]"], 130, 200, s["("], s["N"], 131, 201, s[")"], 2],
+        [s["["], s["N"], s["H"], 130, 200, s["O"], 2],          # unterminated bracket stops at a coordinate id
+        [s["["], s["P"], s["h"], s["]"], 110, 187, s["*"], 140, 170, 3, 150, 175, s["="], 2],
+        [s["C"], 110, 180],                                     # x y at the very end: no following position -> atom dropped
+        [s["C"], 110],                                          # x without y
+        [s["c"], s["1"], 115, 166, s["c"], 116, 167, s["1"], 2],
+        [1, 4, s["C"], 110, 180, 0, s["N"]],                     # <sos>/<mask> mid-sequence, stop at <pad>
+        [s["R"], 101, 228, s["ŕ"], 164, 165, s["~"], s["C"], 2],
+    ]
+    for seq in hand + [ids for ids in decoded_ids]:
+        seq = [int(v) for v in seq]
+        cases.append({"ids": seq, "out": t.sequence_to_smiles(seq)})
+    with open(os.path.join(GOLD, "tokenizer.json"), "w") as f:
+        json.dump({"vocab_size": len(t), "offset": t.offset, "masks": masks, "cases": cases}, f)
+    print("tokenizer:", len(cases), "cases")
+
+
+def gen_e2e(dec, feats):
+    with torch.no_grad():
+        preds = dec.decode(feats)
+    out = []
+    for p in preds:
+        c = p["chartok_coords"]
+        out.append({"smiles": c["smiles"], "symbols": c["symbols"], "coords": c["coords"], "indices": c["indices"],
+                    "edges": p["edges"]})
+    with open(os.path.join(GOLD, "predict_e2e.json"), "w") as f:
+        json.dump({"features": "hash_normal('e2e_features',(4,144,1024),0.5)", "preds": out}, f)
+    print("predict_e2e: atoms", [len(o["symbols"]) for o in out])
+
+
+def main():
+    if not have_reference():
+        raise SystemExit("/root/reference is not mounted: fixtures can only be regenerated in the build container")
+    torch.set_num_threads(8)
+    os.makedirs(GOLD, exist_ok=True)
+    import_reference()
+    from MolNexTR.components import Encoder, Decoder, get_edge_prediction
+    from MolNexTR.models.transformers import Vision_Transformer
+    from MolNexTR.tokenization import get_tokenizer
+    args = reference_args()
+    tok = get_tokenizer(args)
+    with open(os.path.join(ROOT, "molnextr_amd", "vocab", "vocab_chars.json")) as f:
+        assert json.load(f) == tok["chartok_coords"].stoi, "vocab drifted from the reference"
+    ck = W.synthetic_checkpoint(0)
+    gen_swin_tiny(Vision_Transformer)
+    gen_swin_full(Encoder, args, ck)
+    args.encoder_dim = 1024
+    dec = gen_decoder(Decoder, args, tok, ck)
+    gen_edges(dec, get_edge_prediction)
+    g = np.load(os.path.join(GOLD, "decoder_greedy.npz"))
+    decoded = [g["ids"][b, :g["lens"][b]].tolist() for b in range(g["ids"].shape[0])]
+    gen_tokenizer(tok, decoded)
+    gen_e2e(dec, W.hash_normal("e2e_features", (4, 144, 1024), 0.5))
+    sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}
+    print("fixture bytes:", sizes, "total", sum(sizes.values()))
+
+
+if __name__ == "__main__":
+    main()
