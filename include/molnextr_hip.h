@@ -1,0 +1,139 @@
+/* molnextr_hip.h — C ABI of libmolnextr_hip.so, the MI355X (gfx950) engine behind the MolNexTR predict path.
+ *
+ * The reference (CYF2000127/MolNexTR) has no plugin / FFI interface; the seam this library sits behind is the
+ * pair of Python calls in `molnextr.predict_images`
+ *
+ *     features, hiddens = self.encoder(images)                      MolNexTR/model.py:107   (main.py:279)
+ *     batch_predictions = self.decoder.decode(features, hiddens)    MolNexTR/model.py:108   (main.py:280)
+ *
+ * Each entry point below names the reference code it replaces. All functions are `extern "C"`, take plain
+ * pointers and sizes (no torch / C++ types), return 0 on success or a negative mnx_status, never throw, and
+ * enqueue their GPU work on the caller's HIP stream. Device pointers are raw HBM addresses (e.g. a PyTorch-ROCm
+ * tensor's data_ptr()). A handle is bound to one device and is not re-entrant: one in-flight call per handle;
+ * different handles (GPUs) may be driven from different threads or processes. There is no global mutable state.
+ */
+#ifndef MOLNEXTR_HIP_H
+#define MOLNEXTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNX_ABI_VERSION 1
+
+typedef struct mnx_engine mnx_engine;
+
+typedef enum {
+    MNX_OK = 0,
+    MNX_ERR_INVALID_ARG = -1,   /* bad pointer / size / config                                   */
+    MNX_ERR_WEIGHTS = -2,       /* a tensor of the weight contract is missing or has a wrong shape */
+    MNX_ERR_HIP = -3,           /* a HIP runtime call failed (see mnx_last_error)                 */
+    MNX_ERR_NO_DEVICE = -4,     /* no gfx950 device at the requested index                        */
+    MNX_ERR_CAPACITY = -5       /* batch / length / atom count exceeds what mnx_create reserved   */
+} mnx_status;
+
+enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1 };   /* operand type of the encoder MFMA GEMMs */
+
+/* Architecture + capacity. Defaults of the reference inference config are in the comments
+ * (MolNexTR/models/transformers.py:547-551 swin_base; MolNexTR/model.py:50-81; MolNexTR/utils.py:25). */
+typedef struct {
+    int32_t img_size;        /* 384 */
+    int32_t patch;           /* 4   */
+    int32_t embed_dim;       /* 128 */
+    int32_t n_stages;        /* 4   */
+    int32_t depths[4];       /* 2,2,18,2   */
+    int32_t heads[4];        /* 4,8,16,32  (head_dim must be 32) */
+    int32_t window;          /* 12 */
+    int32_t dec_layers;      /* 6   */
+    int32_t dec_dim;         /* 256 */
+    int32_t dec_heads;       /* 8   */
+    int32_t dec_ff;          /* 1024 */
+    int32_t vocab;           /* 229 = 101 symbols + 64 x-bins + 64 y-bins */
+    int32_t sym_offset;      /* 101: first x-bin id */
+    int32_t coord_bins;      /* 64  */
+    int32_t pe_len;          /* 5000 */
+    int32_t max_len;         /* 480: decode capacity (FORMAT_INFO['chartok_coords']['max_len']) */
+    int32_t max_batch;       /* images per mnx_encode call the workspace is sized for */
+    int32_t max_atoms;       /* kmax of mnx_edges (<= max_len / 3) */
+    int32_t compute_dtype;   /* MNX_DTYPE_BF16 */
+} mnx_config;
+
+/* One named fp32 tensor of the checkpoint, in HOST memory. Names are the reference state-dict keys
+ * ("transformer.layers.2.blocks.7.attn.qkv.weight", "decoder.chartok_coords.output_layer.bias", ...).
+ * Index buffers (relative_position_index) and pe.pe are validated/recomputed, pass them or not. */
+typedef struct {
+    const char* name;
+    const float* data;
+    int32_t ndim;
+    int64_t shape[4];
+} mnx_weight_desc;
+
+int mnx_abi_version(void);
+
+/* Replaces `molnextr._get_model` + `loading` (MolNexTR/model.py:17-28,83-95): copies and packs the weights
+ * into HBM (engine-owned), validates EVERY tensor of the contract by name and shape (the reference loads with
+ * strict=False and ignores mismatches), and reserves all workspace for max_batch images — no allocation
+ * happens after create. On failure *out is NULL and the message is available via mnx_last_error(NULL). */
+int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_weights, int32_t device,
+               mnx_engine** out);
+void mnx_destroy(mnx_engine* h);
+
+/* NUL-terminated description of the last error on this handle (or of the last failed mnx_create if h==NULL). */
+const char* mnx_last_error(const mnx_engine* h);
+size_t mnx_workspace_bytes(const mnx_engine* h);
+
+/* Replaces `Encoder.forward` -> `Vision_Transformer.forward` (MolNexTR/components.py:162-174,
+ * MolNexTR/models/transformers.py:504-515). images: device fp32 [B,3,S,S] NCHW, normalised.
+ * features_out: device fp32 [B, (S/32)^2, 8*embed_dim]. Asynchronous on `stream`. */
+int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_out, void* stream);
+
+/* Debug/test aid: copy the fp32 residual stream after execution item `item` of the next mnx_encode calls into
+ * `dst` (device). Items: 0 = patch_embed, then every Swin block and every patch-merging in execution order.
+ * item < 0 disables. */
+int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst);
+
+/* Replaces `TransformerDecoderAR.decode(beam_size=1)` (MolNexTR/components.py:253-334) including enc_transform
+ * (:206-216), Embeddings with the batch-row positional-encoding quirk (MolNexTR/models/embedding.py:52-59),
+ * TransformerDecoder stepwise forward (MolNexTR/models/decoder.py:431-486), output layer + log_softmax +
+ * CharTokenizer.get_output_mask grammar (MolNexTR/tokenization.py:383-392) and GreedySearch
+ * (MolNexTR/decoding/greedy_search.py:96-191).
+ *   features   device fp32 [B,144,1024]                          B <= 32 per call
+ *   chunk_id   device int32 [B] or NULL: rows with equal ids emulate ONE reference batch — row r gets the
+ *              positional encoding of its rank among the still-undecoded rows of its chunk, as the reference
+ *              does when it compacts finished rows out of the batch. NULL = all rows are one batch.
+ *   max_len    <= cfg.max_len; rows stop at EOS or at max_len tokens (reference max_length)
+ *   stop_on_eos 1 = reference behaviour; 0 = fixed-length decode (bench/test aid)
+ *   tokens     device int32 [B,max_len]   ids without SOS, including EOS; entries >= lengths[b] are undefined
+ *   lengths    device int32 [B]
+ *   token_logp device fp32 [B,max_len] or NULL   log-prob of each emitted token (post-mask)
+ *   hidden     device fp32 [B,max_len,256] or NULL   post-final-LayerNorm decoder outputs (input of mnx_edges)
+ *   logits_trace device fp32 [max_len,B,vocab] or NULL (test aid: raw output_layer logits of every step)
+ * Synchronous with respect to its outputs: returns after the last step has completed on `stream`. */
+int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
+                      int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, float* token_logp, float* hidden,
+                      float* logits_trace, void* stream);
+
+/* Replaces the 'edges' branch of `Decoder.decode` (MolNexTR/components.py:470-491): GraphPredictor.forward
+ * (:365-380), softmax over the 7 bond classes and get_edge_prediction (:383-400) incl. its float64 averaging.
+ *   hidden   device fp32 [B,max_len,256] as written by mnx_decode_greedy
+ *   atom_idx device int32 [B,kmax]: decoder position of each atom (CharTokenizer.sequence_to_smiles 'indices')
+ *   n_atoms  device int32 [B]
+ *   edges    device uint8 [B,kmax,kmax] bond class 0..6 (rows/cols >= n_atoms[b] undefined)
+ *   scores   device fp64 [B,kmax,kmax] or NULL
+ * Asynchronous on `stream`. */
+int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const int32_t* n_atoms, int32_t B,
+              int32_t kmax, int32_t max_len, uint8_t* edges, double* scores, void* stream);
+
+/* Kernel-level timing aid for bench.py: runs the 16-bit MFMA GEMM of the encoder on caller buffers.
+ * C[M,N] = A[M,K] . W[N,K]^T + bias, A/W 16-bit device, epi: 0 bias->16-bit, 1 bias+GELU->16-bit,
+ * 2 bias+residual(fp32, in place in C), 3 bias->fp32. */
+int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C, const float* bias, int32_t M,
+               int32_t N, int32_t K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLNEXTR_HIP_H */

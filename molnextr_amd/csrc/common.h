@@ -1,0 +1,56 @@
+// molnextr_amd/csrc/common.h — shared device/host helpers for libmolnextr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MNX_WAVE 64
+
+// 16-bit GEMM operand type traits: the MFMA that consumes it.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct H16<f16_t> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU, as nn.GELU / F.gelu default (reference transformers.py:201, components.py:356, onmt 'gelu')
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// bijective XCD-aware remap of a linear workgroup id (guide T1): consecutive ids land on the same XCD/L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    if (nwg < NX * 2) return bid;
+    int q = nwg / NX, r = nwg % NX;
+    int xcd = bid % NX, k = bid / NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

@@ -1,0 +1,507 @@
+// decoder.hip — autoregressive decoder step, greedy pick, cross-KV/enc_transform SGEMM, bond head.
+//
+// Everything here is fp32 (the decoder is ~1 % of the path's FLOPs but decides every token, so it keeps the
+// reference's precision): SURVEY K6-K12.
+//
+// One decode step = 8 small kernels per layer + 1 "head" kernel, all reading the step index from device memory
+// so the whole step is a fixed hipGraph that the host replays (engine.cpp). Batch rows are fixed slots; a
+// finished row keeps its slot (no compaction on device) and the reference's row renumbering is emulated only
+// where it is observable: the positional-encoding row (see embed prologue).
+#include "common.h"
+#include "kernels.h"
+#include "dec_types.h"
+
+namespace mnx {
+
+// =============================================================================================
+// fp32 SGEMM  C[M,N] = A[M,K] . W[N,K]^T + bias     (enc_transform: reference components.py:206-216;
+// cross-attention K/V projection, once per image: onmt MultiHeadedAttention 'context' cache, driven by
+// reference models/decoder.py:269-276; bond-head first Linear split in two halves: components.py:355-357)
+// 64x64 tile, 16-deep K slices, 4x4 outputs per thread.
+// =============================================================================================
+__global__ __launch_bounds__(256) void sgemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ C, int M,
+                                                       int N, int K) {
+    __shared__ float As[16][68], Ws[16][68];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;
+    const float* ap = A + (size_t)min(m0 + lr, M - 1) * K + lk;
+    const float* wp = W + (size_t)min(n0 + lr, N - 1) * K + lk;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const f32x4 a = *(const f32x4*)(ap + k0), w = *(const f32x4*)(wp + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[lk + j][lr] = a[j];
+            Ws[lk + j][lr] = w[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const f32x4 av = *(const f32x4*)&As[k][ty * 4], wv = *(const f32x4*)&Ws[k][tx * 4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], wv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + tx * 4;
+    if (n >= N) return;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = *(const f32x4*)(bias + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m < M) *(f32x4*)(C + (size_t)m * N + n) = (f32x4){acc[i][0], acc[i][1], acc[i][2], acc[i][3]} + b4;
+    }
+}
+
+hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                           hipStream_t s) {
+    if ((K & 15) || (N & 3)) return hipErrorInvalidValue;
+    dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+    hipLaunchKernelGGL(sgemm_tn_kernel, grid, block, 0, s, A, W, bias, C, M, N, K);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// Skinny linear for the decode step: out[r, n] = epi( pro(in)[r, :] . W[n, :] + b[n] ), r < B <= 32.
+//   One workgroup = 8 output columns x all rows; the [B, 256] input slab is staged in LDS (and layer-normed
+//   there when PRO says so — every workgroup recomputes the tiny LN rather than paying a kernel boundary).
+//   Thread (r = tid & 31, c = tid >> 5).
+// PRO: 0 plain input | 1 LayerNorm(gamma, beta, eps 1e-6) | 2 token embedding + row-PE, then LayerNorm
+// EPI: 0 q/k/v scatter (q scaled, k/v appended to the self cache at position `step`)
+//      1 x[r, n] += result (residual, in place)   2 q-scale store   3 GELU store
+// =============================================================================================
+constexpr int TN = 8, XS = 260;
+
+struct LinArgs {
+    const float* in;      // [B, K]      (PRO 2: unused)
+    const float* W;       // [N, K]
+    const float* bias;    // [N]
+    const float* gamma;   // LN weight / bias (PRO 1, 2)
+    const float* beta;
+    float* out;           // EPI 1: x [B, N] in place; EPI 2/3: [B, N]; EPI 0: q buffer [B, 256]
+    float* kcache;        // EPI 0: this layer's self K cache [B, heads, T, 32]
+    float* vcache;
+    float* x_write;       // PRO 2: residual stream x [B, 256] written by workgroup 0
+    const float* emb;     // PRO 2: [V, 256]
+    const float* pe;      // PRO 2: [pe_len, 256]
+    DecState* st;
+    int B, N, K, T, heads;
+};
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[32 * XS];
+    __shared__ __attribute__((aligned(16))) float ws[TN * XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = tid & 31, c = tid >> 5;
+    const int n0 = blockIdx.x * TN;
+    const int B = a.B;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 256) {
+        // ---- stage the input slab [B, 256] ---------------------------------------------------
+        if (PRO == 2) {
+            // x0[r] = E[tok_r] * sqrt(256) + pe[row_r]; row_r = rank of r among the still-alive rows of its
+            // reference batch chunk — the reference adds a sequence-first PE table to a batch-first tensor and
+            // compacts finished rows out of the batch (components.py:290, embedding.py:52-59,
+            // greedy_search.py:182-190).
+            for (int rr = wave; rr < B; rr += 4) {
+                const int tok = a.st->prev_tok[rr];
+                int rank = 0;
+                for (int q = 0; q < rr; ++q) rank += (a.st->alive[q] != 0 && a.st->chunk[q] == a.st->chunk[rr]);
+                const f32x4 e = *(const f32x4*)(a.emb + (size_t)tok * 256 + lane * 4);
+                const f32x4 p = *(const f32x4*)(a.pe + (size_t)rank * 256 + lane * 4);
+                const f32x4 v = e * 16.0f + p;
+                *(f32x4*)(xs + rr * XS + lane * 4) = v;
+                if (blockIdx.x == 0) *(f32x4*)(a.x_write + rr * 256 + lane * 4) = v;
+            }
+        } else {
+            for (int i = tid; i < B * 64; i += 256) {
+                const int rr = i >> 6, q = i & 63;
+                *(f32x4*)(xs + rr * XS + q * 4) = *(const f32x4*)(a.in + (size_t)rr * a.K + k0 + q * 4);
+            }
+        }
+        for (int i = tid; i < TN * 64; i += 256) {
+            const int nn = i >> 6, q = i & 63;
+            *(f32x4*)(ws + nn * XS + q * 4) = *(const f32x4*)(a.W + (size_t)(n0 + nn) * a.K + k0 + q * 4);
+        }
+        __syncthreads();
+        if (PRO != 0) {  // LayerNorm in place, one wave per row, 4 channels per lane (K == 256)
+            const f32x4 g = *(const f32x4*)(a.gamma + lane * 4), bt = *(const f32x4*)(a.beta + lane * 4);
+            for (int rr = wave; rr < B; rr += 4) {
+                f32x4 v = *(const f32x4*)(xs + rr * XS + lane * 4);
+                const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                v -= mean;
+                const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
+                *(f32x4*)(xs + rr * XS + lane * 4) = v * rsqrtf(var + 1e-6f) * g + bt;
+            }
+            __syncthreads();
+        }
+        const float* xr = xs + r * XS;
+        const float* wr = ws + c * XS;
+#pragma unroll 8
+        for (int k = 0; k < 256; k += 4) {
+            const f32x4 xv = *(const f32x4*)(xr + k), wv = *(const f32x4*)(wr + k);
+            acc = fmaf(xv[0], wv[0], acc);
+            acc = fmaf(xv[1], wv[1], acc);
+            acc = fmaf(xv[2], wv[2], acc);
+            acc = fmaf(xv[3], wv[3], acc);
+        }
+        __syncthreads();
+    }
+    if (r >= B) return;
+    const int n = n0 + c;
+    float v = acc + a.bias[n];
+    if (EPI == 0) {
+        const int part = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
+        if (part == 0) {
+            a.out[r * 256 + ch] = v * 0.17677669529663687f;  // q / sqrt(32) before QK^T (onmt MultiHeadedAttention)
+        } else {
+            const int step = a.st->step;
+            float* cache = part == 1 ? a.kcache : a.vcache;
+            cache[(((size_t)r * a.heads + hd) * a.T + step) * 32 + d] = v;
+        }
+    } else if (EPI == 1) {
+        a.out[(size_t)r * a.N + n] += v;
+    } else if (EPI == 2) {
+        a.out[(size_t)r * a.N + n] = v * 0.17677669529663687f;
+    } else {
+        a.out[(size_t)r * a.N + n] = gelu_erf(v);
+    }
+}
+
+// =============================================================================================
+// Single-query attention, one wave per (row, head): softmax(q.K^T) . V over `nkeys` keys (fp32 throughout,
+// as onmt: scores.float(), no mask for a single query position). Keys of one (row, head) are `kstride`
+// floats apart (32 in the self cache, 2*d_model in the projected memory).
+// =============================================================================================
+struct AttnArgs {
+    const float* q;      // [B, 256] pre-scaled
+    const float* K;      // base of this layer's keys
+    const float* V;
+    float* ctx;          // [B, 256]
+    const DecState* st;
+    long long row_stride, head_stride;   // floats
+    int kstride, fixed_keys, heads;
+};
+
+__global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
+    __shared__ float ps[512];
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
+    const int nkeys = a.fixed_keys > 0 ? a.fixed_keys : a.st->step + 1;
+    const float* Kb = a.K + r * a.row_stride + hd * a.head_stride;
+    const float* Vb = a.V + r * a.row_stride + hd * a.head_stride;
+    f32x4 q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + r * 256 + hd * 32 + i * 4);
+    float sc[8];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int key = lane + j * 64;
+        float s = -3.0e38f;
+        if (key < nkeys) {
+            const float* kp = Kb + (size_t)key * a.kstride;
+            s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 kv = *(const f32x4*)(kp + i * 4);
+                s = fmaf(q[i][0], kv[0], s); s = fmaf(q[i][1], kv[1], s);
+                s = fmaf(q[i][2], kv[2], s); s = fmaf(q[i][3], kv[3], s);
+            }
+        }
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int key = lane + j * 64;
+        if (key < nkeys) {
+            const float p = expf(sc[j] - mx);
+            ps[key] = p;
+            sum += p;
+        }
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const int d = lane & 31, half = lane >> 5;
+    float o = 0.f;
+    for (int key = half; key < nkeys; key += 2) o = fmaf(ps[key], Vb[(size_t)key * a.kstride + d], o);
+    o += __shfl_xor(o, 32, 64);
+    if (lane < 32) a.ctx[r * 256 + hd * 32 + d] = o / sum;
+}
+
+// =============================================================================================
+// Head of the step: final LayerNorm -> hidden state (kept for the bond head) -> output_layer -> log_softmax
+// -> grammar mask -> EOS ban at step 0 -> argmax -> per-row bookkeeping.
+//   reference models/decoder.py:470, components.py:296-306, tokenization.py:383-392,
+//   decode_strategy.py:50-56, greedy_search.py:139-161
+// =============================================================================================
+struct HeadArgs {
+    const float* x;        // [B, 256]
+    const float* gamma;
+    const float* beta;
+    const float* wout_t;   // [256, VP]  (output_layer.weight transposed, padded)
+    const float* bout;     // [V]
+    DecState* st;
+    int* tokens;           // [B, max_len]
+    float* token_logp;     // [B, max_len]
+    float* hidden;         // [B, max_len, 256]
+    float* logits_trace;   // [max_len, B, V] or null
+    int B, V, VP, max_len, x0, y0, eos, stop_on_eos;
+};
+
+__global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
+    __shared__ float hv[256];
+    __shared__ float red[8];
+    __shared__ int redi[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    const int t = a.st->step;
+    if (wave == 0) {
+        f32x4 v = *(const f32x4*)(a.x + r * 256 + lane * 4);
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+        v -= mean;
+        const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
+        const f32x4 o = v * rsqrtf(var + 1e-6f) * *(const f32x4*)(a.gamma + lane * 4) + *(const f32x4*)(a.beta + lane * 4);
+        *(f32x4*)(hv + lane * 4) = o;
+        if (t < a.max_len) *(f32x4*)(a.hidden + ((size_t)r * a.max_len + t) * 256 + lane * 4) = o;
+    }
+    __syncthreads();
+    const bool valid = tid < a.V;
+    float logit = -3.0e38f;
+    if (valid) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 256; ++k) s = fmaf(hv[k], a.wout_t[k * a.VP + tid], s);
+        logit = s + a.bout[tid];
+        if (a.logits_trace && t < a.max_len) a.logits_trace[((size_t)t * a.B + r) * a.V + tid] = logit;
+    }
+    // log_softmax
+    float m = wave_max(logit);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float e = valid ? expf(logit - m) : 0.f;
+    e = wave_sum(e);
+    if (lane == 0) red[4 + wave] = e;
+    __syncthreads();
+    const float lse = m + logf(red[4] + red[5] + red[6] + red[7]);
+    float lp = logit - lse;
+    const int prev = a.st->prev_tok[r];
+    if (prev >= a.x0 && prev < a.y0) { if (tid < a.y0) lp = -10000.0f; }     // after an x-bin: only y-bins
+    else if (prev >= a.y0)           { if (tid >= a.x0) lp = -10000.0f; }    // after a y-bin: no coordinate bins
+    if (t == 0 && tid == a.eos) lp = -1e20f;                                  // min_length = 1
+    if (!valid) lp = -3.0e38f;
+    // argmax, lowest index wins ties (topk(1))
+    float bv = lp;
+    int bi = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
+        if (a.st->alive[r] && t < a.max_len) {
+            a.tokens[(size_t)r * a.max_len + t] = bi;
+            a.token_logp[(size_t)r * a.max_len + t] = bv;
+            a.st->prev_tok[r] = bi;
+            a.st->len[r] = t + 1;
+            if ((a.stop_on_eos && bi == a.eos) || t + 1 >= a.max_len) a.st->alive[r] = 0;
+        }
+    }
+}
+
+// Closes a step: publishes the next step index and the number of rows still decoding (polled by the host).
+// A separate 1-thread kernel: the kernel boundary is the cheapest correct all-rows barrier on this chip.
+__global__ void dec_advance_kernel(DecState* st, int B) {
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int q = 0; q < B; ++q) n += st->alive[q] != 0;
+        st->n_alive = n;
+        st->step = st->step + 1;
+    }
+}
+
+__global__ void dec_init_kernel(DecState* st, const int* chunk, int B, int sos) {
+    const int i = threadIdx.x;
+    if (i == 0) { st->step = 0; st->ticket = 0; st->n_alive = B; }
+    if (i < 32) {
+        st->alive[i] = i < B;
+        st->prev_tok[i] = sos;
+        st->len[i] = 0;
+        st->chunk[i] = (chunk && i < B) ? chunk[i] : 0;
+    }
+}
+
+// ---- host-side enqueue of one decode step (captured into a hipGraph by engine.cpp) ------------
+template <int PRO, int EPI>
+static void lin(hipStream_t s, const LinArgs& a) {
+    hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN), dim3(256), 0, s, a);
+}
+
+hipError_t dec_enqueue_init(const DecBuffers& b, const int* chunk_dev, int B, hipStream_t s) {
+    hipLaunchKernelGGL(dec_init_kernel, dim3(1), dim3(64), 0, s, b.st, chunk_dev, B, 1);
+    return hipGetLastError();
+}
+
+hipError_t dec_enqueue_step(const DecWeights& w, const DecBuffers& b, int B, int max_len, int stop_on_eos,
+                            int* tokens, float* token_logp, float* hidden, float* logits_trace, hipStream_t s) {
+    const int D = 256, H = w.heads, T = b.T;
+    for (int l = 0; l < w.layers; ++l) {
+        const DecLayerW& L = w.L[l];
+        float* kc = b.self_k + (size_t)l * b.max_batch * H * T * 32;
+        float* vc = b.self_v + (size_t)l * b.max_batch * H * T * 32;
+        LinArgs a = {};
+        a.st = b.st; a.B = B; a.T = T; a.heads = H;
+        // LN1 (+ embedding at layer 0) -> q, k, v
+        a.in = b.x; a.W = L.wqkv; a.bias = L.bqkv; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.out = b.q;
+        a.kcache = kc; a.vcache = vc; a.x_write = b.x; a.emb = w.emb; a.pe = w.pe; a.N = 3 * D; a.K = D;
+        if (l == 0) lin<2, 0>(s, a); else lin<1, 0>(s, a);
+        AttnArgs at = {};
+        at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H;
+        at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32; at.fixed_keys = 0;
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(B * H), dim3(64), 0, s, at);
+        // self final_linear + residual
+        a.in = b.ctx; a.W = L.wo; a.bias = L.bo; a.out = b.x; a.N = D; a.K = D;
+        lin<0, 1>(s, a);
+        // LN2 -> context query
+        a.in = b.x; a.W = L.wq2; a.bias = L.bq2; a.gamma = L.ln2_g; a.beta = L.ln2_b; a.out = b.q;
+        lin<1, 2>(s, a);
+        at.K = b.mem_kv + (size_t)l * 2 * D;          // memory K/V: [B*S, layers*2*D], layer l keys then values
+        at.V = at.K + D;
+        at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = 32; at.kstride = w.layers * 2 * D;
+        at.fixed_keys = b.S;
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(B * H), dim3(64), 0, s, at);
+        // context final_linear + residual
+        a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = b.x;
+        lin<0, 1>(s, a);
+        // feed-forward: LN -> w_1 -> GELU -> w_2 -> + residual
+        a.in = b.x; a.W = L.w1; a.bias = L.b1; a.gamma = L.lnf_g; a.beta = L.lnf_b; a.out = b.h; a.N = w.dff;
+        lin<1, 3>(s, a);
+        a.in = b.h; a.W = L.w2; a.bias = L.b2; a.out = b.x; a.N = D; a.K = w.dff;
+        lin<0, 1>(s, a);
+    }
+    HeadArgs h = {};
+    h.x = b.x; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
+    h.tokens = tokens; h.token_logp = token_logp; h.hidden = hidden; h.logits_trace = logits_trace;
+    h.B = B; h.V = w.vocab; h.VP = w.vpad; h.max_len = max_len; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
+    h.eos = 2; h.stop_on_eos = stop_on_eos;
+    hipLaunchKernelGGL(dec_head_kernel, dim3(B), dim3(256), 0, s, h);
+    hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, s, b.st, B);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// Bond head (reference components.py:365-400,478-484)
+//   logits[i,j] = W2 . GELU(W1a.h_i + W1b.h_j + b1) + b2 ; the two halves of the first Linear are applied
+//   once per atom (SGEMM above) instead of once per pair.
+// =============================================================================================
+__global__ void edge_gather_kernel(const float* __restrict__ hidden, const int* __restrict__ atom_idx,
+                                   const int* __restrict__ n_atoms, float* __restrict__ g, int kmax, int max_len) {
+    const int b = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
+    int idx = i < n_atoms[b] ? atom_idx[b * kmax + i] : 0;
+    idx = min(max(idx, 0), max_len - 1);
+    *(f32x4*)(g + ((size_t)b * kmax + i) * 256 + lane * 4) =
+        *(const f32x4*)(hidden + ((size_t)b * max_len + idx) * 256 + lane * 4);
+}
+
+// UV [B*kmax, 512]: cols 0..255 = W1a.h (+0), cols 256..511 = W1b.h + b1.  One workgroup per (b, i); lane = j.
+__global__ __launch_bounds__(256) void edge_pair_kernel(const float* __restrict__ UV, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, const int* __restrict__ n_atoms,
+                                                        float* __restrict__ prob, int kmax) {
+    __shared__ float us[256];
+    __shared__ float w2s[7 * 256];
+    const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+    const int k = n_atoms[b];
+    if (i >= k) return;
+    us[tid] = UV[((size_t)b * kmax + i) * 512 + tid];
+    for (int q = tid; q < 7 * 256; q += 256) w2s[q] = w2[q];
+    __syncthreads();
+    for (int j = tid; j < k; j += 256) {
+        const float* vp = UV + ((size_t)b * kmax + j) * 512 + 256;
+        float o[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) o[c] = b2[c];
+        for (int ch = 0; ch < 256; ch += 4) {
+            const f32x4 v = *(const f32x4*)(vp + ch);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float z = gelu_erf(us[ch + u] + v[u]);
+#pragma unroll
+                for (int c = 0; c < 7; ++c) o[c] = fmaf(z, w2s[c * 256 + ch + u], o[c]);
+            }
+        }
+        float m = o[0];
+#pragma unroll
+        for (int c = 1; c < 7; ++c) m = fmaxf(m, o[c]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) { o[c] = expf(o[c] - m); sum += o[c]; }
+        float* pp = prob + (((size_t)b * kmax + i) * kmax + j) * 8;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) pp[c] = o[c] / sum;
+    }
+}
+
+// get_edge_prediction (components.py:383-400): averages are taken in float64 on float32 probabilities, exactly
+// as the reference does on Python float lists; argmax = first maximum.
+__global__ void edge_sym_kernel(const float* __restrict__ prob, const int* __restrict__ n_atoms,
+                                unsigned char* __restrict__ edges, double* __restrict__ scores, int kmax) {
+    const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = n_atoms[b];
+    if (i >= k || j >= k) return;
+    const float* pij = prob + (((size_t)b * kmax + i) * kmax + j) * 8;
+    const float* pji = prob + (((size_t)b * kmax + j) * kmax + i) * 8;
+    double e[7];
+    if (i == j) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) e[c] = (double)pij[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) e[c] = i < j ? ((double)pij[c] + (double)pji[c]) / 2 : ((double)pji[c] + (double)pij[c]) / 2;
+        if (i < j) {
+            e[5] = ((double)pij[5] + (double)pji[6]) / 2;
+            e[6] = ((double)pij[6] + (double)pji[5]) / 2;
+        } else {  // lower triangle mirrors the upper one with 5 <-> 6 swapped
+            e[5] = ((double)pji[6] + (double)pij[5]) / 2;
+            e[6] = ((double)pji[5] + (double)pij[6]) / 2;
+        }
+    }
+    int best = 0;
+    double bv = e[0];
+#pragma unroll
+    for (int c = 1; c < 7; ++c)
+        if (e[c] > bv) { bv = e[c]; best = c; }
+    edges[((size_t)b * kmax + i) * kmax + j] = (unsigned char)best;
+    if (scores) scores[((size_t)b * kmax + i) * kmax + j] = bv;
+}
+
+hipError_t edges_enqueue(const DecWeights& w, const DecBuffers& bf, const float* hidden, const int* atom_idx,
+                         const int* n_atoms, int B, int kmax, int max_len, unsigned char* edges, double* scores,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(edge_gather_kernel, dim3(kmax, B), dim3(64), 0, s, hidden, atom_idx, n_atoms, bf.edge_g, kmax,
+                       max_len);
+    hipError_t e = launch_sgemm_tn(bf.edge_g, w.edge_w1cat, w.edge_b1cat, bf.edge_uv, B * kmax, 512, 256, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(edge_pair_kernel, dim3(kmax, B), dim3(256), 0, s, bf.edge_uv, w.edge_w2, w.edge_b2, n_atoms,
+                       bf.edge_prob, kmax);
+    hipLaunchKernelGGL(edge_sym_kernel, dim3((kmax + 63) / 64, kmax, B), dim3(64), 0, s, bf.edge_prob, n_atoms, edges,
+                       scores, kmax);
+    return hipGetLastError();
+}
+
+}  // namespace mnx

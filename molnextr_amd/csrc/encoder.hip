@@ -1,0 +1,350 @@
+// encoder.hip — non-GEMM kernels of the Swin encoder.
+//
+// Activations are token-major [B, L, C] (= channels-last). The residual stream is fp32; the operands of the
+// MFMA GEMMs are produced here as 16-bit (bf16 by default).
+#include "common.h"
+#include "kernels.h"
+
+namespace mnx {
+
+// =============================================================================================
+// K1  patch embedding: Conv2d(3, C, k=4, s=4) + bias -> LayerNorm(C)     (reference transformers.py:405-419)
+//     One workgroup = 32 consecutive patches of one patch-row; one wave normalises one patch at a time
+//     (lane owns channels lane and lane+64), so the LayerNorm reduction is a wavefront reduction.
+// =============================================================================================
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w_t,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ x,
+                                                          int S, int C, int G) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wt = sm;             // [48][C]
+    float* pix = sm + 48 * C;   // [3][4][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px0 = blockIdx.x * 32, py = blockIdx.y, b = blockIdx.z;
+    for (int i = tid; i < 48 * C; i += 256) wt[i] = w_t[i];
+    for (int i = tid; i < 3 * 4 * 128; i += 256) {
+        int ci = i >> 9, ky = (i >> 7) & 3, xx = i & 127;
+        int gx = px0 * 4 + xx;
+        pix[i] = gx < S ? img[((size_t)(b * 3 + ci) * S + (py * 4 + ky)) * S + gx] : 0.f;
+    }
+    __syncthreads();
+    const bool c0 = lane < C, c1 = lane + 64 < C;
+    const float b0 = c0 ? bias[lane] : 0.f, b1 = c1 ? bias[lane + 64] : 0.f;
+    const float g0 = c0 ? gamma[lane] : 0.f, g1 = c1 ? gamma[lane + 64] : 0.f;
+    const float e0 = c0 ? beta[lane] : 0.f, e1 = c1 ? beta[lane + 64] : 0.f;
+    for (int p = wave * 8; p < wave * 8 + 8; ++p) {
+        const int px = px0 + p;
+        if (px >= G) break;
+        float a0 = b0, a1 = b1;
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+            const float v = pix[((i >> 2) << 7) + p * 4 + (i & 3)];  // (ci*4+ky)*128 + p*4 + kx
+            if (c0) a0 = fmaf(v, wt[i * C + lane], a0);
+            if (c1) a1 = fmaf(v, wt[i * C + lane + 64], a1);
+        }
+        const float mean = wave_sum((c0 ? a0 : 0.f) + (c1 ? a1 : 0.f)) / (float)C;
+        const float d0 = c0 ? a0 - mean : 0.f, d1 = c1 ? a1 - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)C + 1e-5f);
+        float* o = x + ((size_t)(b * G + py) * G + px) * C;
+        if (c0) o[lane] = d0 * rstd * g0 + e0;
+        if (c1) o[lane + 64] = d1 * rstd * g1 + e1;
+    }
+}
+
+hipError_t launch_patch_embed(const float* img, const float* w_t, const float* bias, const float* gamma,
+                              const float* beta, float* x, int B, int S, int C, hipStream_t s) {
+    if (C > 128 || (S & 3)) return hipErrorInvalidValue;
+    const int G = S / 4;
+    dim3 grid((G + 31) / 32, G, B), block(256);
+    size_t smem = (size_t)(48 * C + 3 * 4 * 128) * sizeof(float);
+    hipLaunchKernelGGL(patch_embed_kernel, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, C, G);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// K2  LayerNorm over the channel dim, fp32 in -> 16-bit out (GEMM operand) [+ fp32 out].  One wave per row.
+//     MERGE=true fuses the PatchMerging 2x2 gather (reference transformers.py:325-333): logical row
+//     (b, y2, x2) is the concat of x[b, 2y2+dy, 2x2+dx, :] for (dy,dx) = (0,0),(1,0),(0,1),(1,1).
+// =============================================================================================
+template <typename T, bool MERGE, int NV>
+__global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y16,
+                                                          float* __restrict__ y32, int M, int C, float eps, int H,
+                                                          int W, int Cin) {
+    typedef typename H16<T>::v4 v4;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* src[4];
+    if (MERGE) {
+        const int W2 = W >> 1, H2 = H >> 1;
+        const int x2 = row % W2, y2 = (row / W2) % H2, b = row / (W2 * H2);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            src[p] = x + ((size_t)(b * H + 2 * y2 + (p & 1)) * W + 2 * x2 + (p >> 1)) * Cin;
+    } else {
+        src[0] = x + (size_t)row * C;
+    }
+    f32x4 v[NV];  // C <= 256 * NV
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = lane * 4 + j * 256;
+        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (e < C) {
+            if (MERGE) {
+                const int p = e / Cin;
+                v[j] = *(const f32x4*)(src[p] + (e - p * Cin));
+            } else {
+                v[j] = *(const f32x4*)(src[0] + e);
+            }
+            sum += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = lane * 4 + j * 256;
+        if (e < C) {
+            v[j] -= mean;
+            sq += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = lane * 4 + j * 256;
+        if (e < C) {
+            const f32x4 g = *(const f32x4*)(gamma + e), bt = *(const f32x4*)(beta + e);
+            const f32x4 o = v[j] * rstd * g + bt;
+            if (y16) {
+                v4 o4 = {(T)o[0], (T)o[1], (T)o[2], (T)o[3]};
+                *(v4*)(y16 + (size_t)row * C + e) = o4;
+            }
+            if (y32) *(f32x4*)(y32 + (size_t)row * C + e) = o;
+        }
+    }
+}
+
+template <typename T, bool MERGE>
+static void ln_dispatch(dim3 grid, hipStream_t s, const float* x, const float* gamma, const float* beta, T* y16,
+                        float* y32, int M, int C, float eps, int H, int W, int Cin) {
+    dim3 block(256);
+    if (C <= 256)
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 1>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+    else if (C <= 512)
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 2>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+    else if (C <= 1024)
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 4>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+    else
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 8>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+}
+
+hipError_t launch_layernorm16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, float* y32,
+                              int M, int C, float eps, hipStream_t s) {
+    if (C > 2048 || (C & 3)) return hipErrorInvalidValue;
+    dim3 grid((M + 3) / 4);
+    if (dtype == MNX_DT_F16)
+        ln_dispatch<f16_t, false>(grid, s, x, gamma, beta, (f16_t*)y16, y32, M, C, eps, 0, 0, 0);
+    else
+        ln_dispatch<bf16_t, false>(grid, s, x, gamma, beta, (bf16_t*)y16, y32, M, C, eps, 0, 0, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_ln16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, int B, int H,
+                             int W, int C, float eps, hipStream_t s) {
+    if (4 * C > 2048 || (C & 3) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
+    const int M = B * (H / 2) * (W / 2);
+    dim3 grid((M + 3) / 4);
+    if (dtype == MNX_DT_F16)
+        ln_dispatch<f16_t, true>(grid, s, x, gamma, beta, (f16_t*)y16, nullptr, M, 4 * C, eps, H, W, C);
+    else
+        ln_dispatch<bf16_t, true>(grid, s, x, gamma, beta, (bf16_t*)y16, nullptr, M, 4 * C, eps, H, W, C);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void cast16_kernel(const float* __restrict__ x, T* __restrict__ y, size_t n4) {
+    typedef typename H16<T>::v4 v4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        v4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        *(v4*)(y + i * 4) = o;
+    }
+}
+
+hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStream_t s) {
+    if (n & 3) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    dim3 grid((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)), block(256);
+    if (dtype == MNX_DT_F16)
+        hipLaunchKernelGGL((cast16_kernel<f16_t>), grid, block, 0, s, x, (f16_t*)y16, n4);
+    else
+        hipLaunchKernelGGL((cast16_kernel<bf16_t>), grid, block, 0, s, x, (bf16_t*)y16, n4);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// K4  (shifted-)window attention, window 12x12 = 144 tokens, head_dim 32
+//     (reference transformers.py:68-97 partition/reverse, :147-178 attention, :220-243 shift mask, :260-282 roll)
+//
+//     One workgroup (3 waves) per (image, window, head). The cyclic shift, the window partition and their
+//     inverses are index arithmetic on the token row — nothing is materialised: the kernel reads q,k,v of
+//     the 144 window tokens straight from the [B*L, 3C] qkv buffer and writes the head's 32 output channels
+//     back at the tokens' ORIGINAL rows. Scores live in MFMA accumulators only.
+//
+//     S^T = K.Q^T is computed key-major ("swapped") so every lane owns ONE query column: softmax statistics
+//     are 36 in-register values + two cross-lane steps, and the exponentiated probabilities are already in
+//     the B-operand layout of the second MFMA  O^T = V^T.P^T  (V is transposed once through LDS). The k-slot
+//     order of that MFMA is permuted identically on both operands so no data movement is needed.
+// =============================================================================================
+constexpr int WS = 12, WN = 144, HD = 32;
+constexpr int KS_STRIDE = 40;    // elements per K row in LDS (80 B: conflict-free ds_read_b128)
+constexpr int VT_STRIDE = 168;   // elements per V^T row in LDS (336 B: conflict-free ds_read_b64), keys 144..167 zero
+
+template <typename T>
+__global__ __launch_bounds__(192) void window_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
+                                                          T* __restrict__ out, int H, int W, int C, int heads,
+                                                          int shift) {
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) T Ks[WN * KS_STRIDE];
+    __shared__ __attribute__((aligned(16))) T Vt[HD * VT_STRIDE];
+    __shared__ float tab[(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int rowof[WN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nWw = W / WS, nWh = H / WS;
+    int bid = blockIdx.x;
+    const int head = bid % heads; bid /= heads;
+    const int wx = bid % nWw; bid /= nWw;
+    const int wy = bid % nWh;
+    const int b = bid / nWh;
+
+    for (int t = tid; t < WN; t += 192) {
+        int ys = wy * WS + t / WS, xs = wx * WS + t % WS;
+        int yo = ys + shift; if (yo >= H) yo -= H;
+        int xo = xs + shift; if (xo >= W) xo -= W;
+        rowof[t] = (b * H + yo) * W + xo;
+    }
+    for (int i = tid; i < 529; i += 192) tab[i] = table[i * heads + head];
+    for (int i = tid; i < HD * (VT_STRIDE - WN); i += 192)
+        Vt[(i / (VT_STRIDE - WN)) * VT_STRIDE + WN + i % (VT_STRIDE - WN)] = (T)0.f;
+    __syncthreads();
+
+    const size_t ld = (size_t)3 * C;
+    for (int i = tid; i < WN * 4; i += 192) {       // 576 16-byte chunks each for K and V
+        const int key = i >> 2, g8 = i & 3;
+        const T* base = qkv + (size_t)rowof[key] * ld + head * HD + g8 * 8;
+        const v8 kv = *(const v8*)(base + C);
+        const v8 vv = *(const v8*)(base + 2 * C);
+        *(v8*)(Ks + key * KS_STRIDE + g8 * 8) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(g8 * 8 + j) * VT_STRIDE + key] = vv[j];
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    v8 qf[3];
+    int qrow[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        qrow[q] = rowof[(wave * 3 + q) * 16 + fr];
+        qf[q] = *(const v8*)(qkv + (size_t)qrow[q] * ld + head * HD + fg * 8);
+    }
+    __syncthreads();
+
+    // ---- S^T[key][query] -------------------------------------------------------------------
+    f32x4 acc[3][9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+        const v8 kf = *(const v8*)(Ks + (kt * 16 + fr) * KS_STRIDE + fg * 8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            acc[q][kt] = H16<T>::mfma(kf, qf[q], (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
+
+    // ---- scale + relative-position bias + shift mask, softmax over keys ----------------------
+    const float scale = 0.17677669529663687f;  // 32^-0.5 (reference scales q before QK^T; same product)
+    const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
+    float inv_sum[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int qi = (wave * 3 + q) * 16 + fr;
+        const int qy = qi / WS, qx = qi % WS;
+        const int rq = (last_y ? (qy < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (qx < WS - shift ? 1 : 2) : 0);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ki = kt * 16 + fg * 4 + r;
+                const int ky = ki / WS, kx = ki % WS;
+                const int rk = (last_y ? (ky < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (kx < WS - shift ? 1 : 2) : 0);
+                float s = acc[q][kt][r] * scale + tab[(qy - ky + WS - 1) * (2 * WS - 1) + (qx - kx + WS - 1)];
+                if (rq != rk) s += -100.0f;
+                acc[q][kt][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(acc[q][kt][r] - mx);
+                acc[q][kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        inv_sum[q] = 1.0f / sum;
+    }
+
+    // ---- O^T[d][query] = V^T . P^T over 5 blocks of 32 key slots (last block half zero) -------
+    f32x4 oacc[3][2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) oacc[q][0] = oacc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        v8 pf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const f32x4 lo = acc[q][2 * m];
+            const f32x4 hi = (m < 4) ? acc[q][m < 4 ? 2 * m + 1 : 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            pf[q] = (v8){(T)lo[0], (T)lo[1], (T)lo[2], (T)lo[3], (T)hi[0], (T)hi[1], (T)hi[2], (T)hi[3]};
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const T* vrow = Vt + (dt * 16 + fr) * VT_STRIDE + m * 32 + fg * 4;
+            const v4 a = *(const v4*)vrow, c = *(const v4*)(vrow + 16);
+            const v8 vf = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) oacc[q][dt] = H16<T>::mfma(vf, pf[q], oacc[q][dt]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const f32x4 o = oacc[q][dt] * inv_sum[q];
+            v4 o4 = {(T)o[0], (T)o[1], (T)o[2], (T)o[3]};
+            *(v4*)(out + (size_t)qrow[q] * C + head * HD + dt * 16 + fg * 4) = o4;
+        }
+}
+
+hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,
+                              int C, int heads, int shift, hipStream_t s) {
+    if (C != heads * HD || H % WS || W % WS) return hipErrorInvalidValue;
+    dim3 grid(B * (H / WS) * (W / WS) * heads), block(192);
+    if (dtype == MNX_DT_F16)
+        hipLaunchKernelGGL((window_attn_kernel<f16_t>), grid, block, 0, s, (const f16_t*)qkv16, rel_table,
+                           (f16_t*)out16, H, W, C, heads, shift);
+    else
+        hipLaunchKernelGGL((window_attn_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)qkv16, rel_table,
+                           (bf16_t*)out16, H, W, C, heads, shift);
+    return hipGetLastError();
+}
+
+}  // namespace mnx

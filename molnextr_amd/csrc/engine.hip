@@ -1,0 +1,612 @@
+// engine.hip — host side of libmolnextr_hip.so: weight packing, workspace, encode/decode/edges orchestration,
+// hipGraph replay of the decode step. Implements include/molnextr_hip.h.
+#include "../../include/molnextr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "dec_types.h"
+#include "kernels.h"
+
+using namespace mnx;
+
+namespace {
+
+std::string g_create_error;
+
+struct BlockW {
+    float *ln1_g, *ln1_b, *table, *qkv_b, *proj_b, *ln2_g, *ln2_b, *fc1_b, *fc2_b;
+    void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+struct StageW {
+    std::vector<BlockW> blocks;
+    float *m_g = nullptr, *m_b = nullptr;
+    void* m_w = nullptr;
+    int C = 0, heads = 0;
+};
+struct GraphKey {
+    int B, max_len, stop, trace;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(B, max_len, stop, trace) < std::tie(o.B, o.max_len, o.stop, o.trace);
+    }
+};
+
+}  // namespace
+
+struct mnx_engine {
+    mnx_config cfg;
+    int device = 0;
+    std::string err;
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+    // encoder
+    float *pe_wt = nullptr, *pe_b = nullptr, *pe_g = nullptr, *pe_beta = nullptr, *fn_g = nullptr, *fn_b = nullptr;
+    std::vector<StageW> stages;
+    float *xa = nullptr, *xb = nullptr;              // fp32 residual stream ping-pong
+    void *xn16 = nullptr, *qkv16 = nullptr, *attn16 = nullptr, *h16 = nullptr;
+    int tap_item = -1;
+    float* tap_dst = nullptr;
+    // decoder
+    DecWeights dw{};
+    DecBuffers db{};
+    int *out_tokens = nullptr, *out_len_dummy = nullptr;
+    float *out_logp = nullptr, *out_hidden = nullptr, *out_trace = nullptr;
+    int* host_flag = nullptr;  // pinned
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    bool use_graph = true;
+    hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                 \
+            return MNX_ERR_HIP;                                                                           \
+        }                                                                                                 \
+    } while (0)
+
+struct Packer {
+    mnx_engine* h;
+    std::unordered_map<std::string, const mnx_weight_desc*> by_name;
+    std::vector<std::string> problems;
+    float* staging = nullptr;
+    size_t staging_elems = 0;
+
+    const mnx_weight_desc* find(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) {
+            problems.push_back("missing " + name);
+            return nullptr;
+        }
+        const mnx_weight_desc* d = it->second;
+        bool ok = d->ndim == (int)shape.size() && d->data != nullptr;
+        int i = 0;
+        for (int64_t s : shape) ok = ok && d->shape[i++] == s;
+        if (!ok) {
+            std::string got = "[";
+            for (int k = 0; k < d->ndim; ++k) got += std::to_string(d->shape[k]) + (k + 1 < d->ndim ? "," : "");
+            problems.push_back("shape " + name + ": got " + got + "]");
+            return nullptr;
+        }
+        return d;
+    }
+    void* dalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+            problems.push_back("hipMalloc failed for " + std::to_string(bytes) + " bytes");
+            return nullptr;
+        }
+        h->allocs.push_back(p);
+        h->bytes += bytes;
+        return p;
+    }
+    float* up32(const float* host, size_t n) {
+        float* p = (float*)dalloc(n * sizeof(float));
+        if (p && hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            problems.push_back("hipMemcpy H2D failed");
+        return p;
+    }
+    float* f32(const std::string& name, std::initializer_list<int64_t> shape) {
+        const mnx_weight_desc* d = find(name, shape);
+        if (!d) return nullptr;
+        size_t n = 1;
+        for (int64_t s : shape) n *= (size_t)s;
+        return up32(d->data, n);
+    }
+    void* w16(const std::string& name, std::initializer_list<int64_t> shape) {
+        const mnx_weight_desc* d = find(name, shape);
+        if (!d) return nullptr;
+        size_t n = 1;
+        for (int64_t s : shape) n *= (size_t)s;
+        if (n > staging_elems) {
+            problems.push_back("staging too small for " + name);
+            return nullptr;
+        }
+        void* p = dalloc(n * 2);
+        if (!p) return nullptr;
+        if (hipMemcpy(staging, d->data, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            launch_cast16(h->cfg.compute_dtype, staging, p, n, 0) != hipSuccess ||
+            hipStreamSynchronize(0) != hipSuccess)
+            problems.push_back("convert failed for " + name);
+        return p;
+    }
+    const float* host(const std::string& name, std::initializer_list<int64_t> shape) {
+        const mnx_weight_desc* d = find(name, shape);
+        return d ? d->data : nullptr;
+    }
+};
+
+int check_cfg(const mnx_config& c, std::string& why) {
+    auto bad = [&](const char* m) { why = m; return MNX_ERR_INVALID_ARG; };
+    if (c.n_stages < 1 || c.n_stages > 4) return bad("n_stages must be 1..4");
+    if (c.patch != 4) return bad("patch must be 4");
+    if (c.window != 12) return bad("window must be 12");
+    if (c.embed_dim % 32 || c.embed_dim > 128) return bad("embed_dim must be 32..128, multiple of 32");
+    int g = c.img_size / c.patch;
+    if (c.img_size % c.patch) return bad("img_size not a multiple of patch");
+    for (int s = 0; s < c.n_stages; ++s) {
+        int C = c.embed_dim << s;
+        if (c.heads[s] * 32 != C) return bad("head_dim must be 32 in every stage");
+        if (g % c.window) return bad("every stage's token grid must be a multiple of the window (no padding path)");
+        if (c.depths[s] < 1) return bad("depth < 1");
+        if (s + 1 < c.n_stages) {
+            if (g & 1) return bad("odd grid before merge");
+            g /= 2;
+        }
+    }
+    if (c.dec_dim != 256 || c.dec_heads != 8) return bad("decoder kernels are built for d_model 256, 8 heads");
+    if (c.dec_layers < 1 || c.dec_layers > MAX_DEC_LAYERS) return bad("dec_layers out of range");
+    if (c.dec_ff % 256 || c.dec_ff < 256) return bad("dec_ff must be a multiple of 256");
+    if (c.vocab > 256 || c.vocab != c.sym_offset + 2 * c.coord_bins) return bad("vocab must be sym_offset+2*bins <= 256");
+    if (c.max_len < 1 || c.max_len > 512) return bad("max_len must be 1..512");
+    if (c.max_batch < 1) return bad("max_batch < 1");
+    if (c.max_atoms < 1 || c.max_atoms > 256) return bad("max_atoms must be 1..256");
+    if (c.compute_dtype != MNX_DTYPE_BF16 && c.compute_dtype != MNX_DTYPE_FP16) return bad("compute_dtype");
+    if (c.pe_len < MAX_ROWS) return bad("pe_len too small");
+    return MNX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mnx_abi_version(void) { return MNX_ABI_VERSION; }
+
+const char* mnx_last_error(const mnx_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+size_t mnx_workspace_bytes(const mnx_engine* h) { return h ? h->bytes : 0; }
+
+void mnx_destroy(mnx_engine* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->host_flag) hipHostFree(h->host_flag);
+    delete h;
+}
+
+int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_weights, int32_t device,
+               mnx_engine** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !weights || !out || n_weights <= 0) {
+        g_create_error = "mnx_create: null argument";
+        return MNX_ERR_INVALID_ARG;
+    }
+    std::string why;
+    if (check_cfg(*cfg, why) != MNX_OK) {
+        g_create_error = "mnx_create: bad config: " + why;
+        return MNX_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        g_create_error = "mnx_create: no HIP device " + std::to_string(device) + " (libmolnextr_hip needs an MI355X; there is no CPU fallback)";
+        return MNX_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        g_create_error = "mnx_create: cannot select device";
+        return MNX_ERR_NO_DEVICE;
+    }
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_error = std::string("mnx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return MNX_ERR_NO_DEVICE;
+    }
+    mnx_engine* h = new mnx_engine();
+    h->cfg = *cfg;
+    h->device = device;
+    const char* ng = getenv("MNX_NO_GRAPH");
+    h->use_graph = !(ng && ng[0] == '1');
+    Packer P;
+    P.h = h;
+    for (int i = 0; i < n_weights; ++i)
+        if (weights[i].name) P.by_name[weights[i].name] = &weights[i];
+    const mnx_config& c = h->cfg;
+
+    // staging buffer for fp32 -> 16-bit conversion: the largest GEMM weight
+    size_t max_w = 0;
+    for (int s = 0; s < c.n_stages; ++s) {
+        size_t C = (size_t)c.embed_dim << s;
+        max_w = std::max(max_w, 4 * C * C);
+        if (s + 1 < c.n_stages) max_w = std::max(max_w, 8 * C * C);
+    }
+    P.staging_elems = max_w;
+    if (hipMalloc((void**)&P.staging, max_w * sizeof(float)) != hipSuccess) {
+        g_create_error = "mnx_create: hipMalloc(staging) failed";
+        delete h;
+        return MNX_ERR_HIP;
+    }
+
+    // ---------------- encoder weights ----------------
+    const std::string T = "transformer.";
+    {
+        const int C = c.embed_dim;
+        const float* pw = P.host(T + "patch_embed.proj.weight", {C, 3, 4, 4});
+        if (pw) {  // [C][48] -> [48][C]
+            std::vector<float> wt((size_t)48 * C);
+            for (int ch = 0; ch < C; ++ch)
+                for (int i = 0; i < 48; ++i) wt[(size_t)i * C + ch] = pw[(size_t)ch * 48 + i];
+            h->pe_wt = P.up32(wt.data(), wt.size());
+        }
+        h->pe_b = P.f32(T + "patch_embed.proj.bias", {C});
+        h->pe_g = P.f32(T + "patch_embed.norm.weight", {C});
+        h->pe_beta = P.f32(T + "patch_embed.norm.bias", {C});
+    }
+    const int64_t NT = (2 * c.window - 1) * (2 * c.window - 1);
+    h->stages.resize(c.n_stages);
+    for (int s = 0; s < c.n_stages; ++s) {
+        StageW& st = h->stages[s];
+        const int64_t C = (int64_t)c.embed_dim << s;
+        st.C = (int)C;
+        st.heads = c.heads[s];
+        for (int b = 0; b < c.depths[s]; ++b) {
+            const std::string p = T + "layers." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+            BlockW w{};
+            w.ln1_g = P.f32(p + "norm1.weight", {C});
+            w.ln1_b = P.f32(p + "norm1.bias", {C});
+            w.table = P.f32(p + "attn.relative_position_bias_table", {NT, st.heads});
+            w.qkv_w = P.w16(p + "attn.qkv.weight", {3 * C, C});
+            w.qkv_b = P.f32(p + "attn.qkv.bias", {3 * C});
+            w.proj_w = P.w16(p + "attn.proj.weight", {C, C});
+            w.proj_b = P.f32(p + "attn.proj.bias", {C});
+            w.ln2_g = P.f32(p + "norm2.weight", {C});
+            w.ln2_b = P.f32(p + "norm2.bias", {C});
+            w.fc1_w = P.w16(p + "mlp.fc1.weight", {4 * C, C});
+            w.fc1_b = P.f32(p + "mlp.fc1.bias", {4 * C});
+            w.fc2_w = P.w16(p + "mlp.fc2.weight", {C, 4 * C});
+            w.fc2_b = P.f32(p + "mlp.fc2.bias", {C});
+            st.blocks.push_back(w);
+        }
+        if (s + 1 < c.n_stages) {
+            const std::string p = T + "layers." + std::to_string(s) + ".downsample.";
+            st.m_g = P.f32(p + "norm.weight", {4 * C});
+            st.m_b = P.f32(p + "norm.bias", {4 * C});
+            st.m_w = P.w16(p + "reduction.weight", {2 * C, 4 * C});
+        }
+    }
+    const int64_t CF = (int64_t)c.embed_dim << (c.n_stages - 1);
+    h->fn_g = P.f32(T + "norm.weight", {CF});
+    h->fn_b = P.f32(T + "norm.bias", {CF});
+
+    // ---------------- decoder weights ----------------
+    DecWeights& dw = h->dw;
+    const int64_t D = c.dec_dim, FF = c.dec_ff, V = c.vocab;
+    const int64_t S = (int64_t)(c.img_size / c.patch >> (c.n_stages - 1)) * (c.img_size / c.patch >> (c.n_stages - 1));
+    dw.layers = c.dec_layers; dw.heads = c.dec_heads; dw.dff = c.dec_ff; dw.vocab = c.vocab; dw.vpad = (c.vocab + 7) & ~7;
+    dw.sym_offset = c.sym_offset; dw.bins = c.coord_bins; dw.pe_len = c.pe_len; dw.enc_dim = (int)CF;
+    const std::string Dp = "decoder.chartok_coords.";
+    dw.w_enc = P.f32(Dp + "enc_trans_layer.0.weight", {D, CF});
+    dw.b_enc = P.f32(Dp + "enc_trans_layer.0.bias", {D});
+    dw.lnF_g = P.f32(Dp + "decoder.layer_norm.weight", {D});
+    dw.lnF_b = P.f32(Dp + "decoder.layer_norm.bias", {D});
+    dw.emb = P.f32(Dp + "embeddings.make_embedding.emb_luts.0.weight", {V, D});
+    dw.bout = P.f32(Dp + "output_layer.bias", {V});
+    {
+        const float* wo = P.host(Dp + "output_layer.weight", {V, D});
+        if (wo) {
+            std::vector<float> t((size_t)D * dw.vpad, 0.f);
+            for (int64_t v = 0; v < V; ++v)
+                for (int64_t k = 0; k < D; ++k) t[(size_t)k * dw.vpad + v] = wo[v * D + k];
+            dw.wout_t = P.up32(t.data(), t.size());
+        }
+        // sinusoid table: recomputed exactly as the reference builds it (MolNexTR/models/embedding.py:30-35);
+        // if the checkpoint carries pe.pe it must agree.
+        std::vector<float> pe((size_t)c.pe_len * D);
+        for (int64_t pos = 0; pos < c.pe_len; ++pos)
+            for (int64_t i = 0; i < D; i += 2) {
+                const float div = expf((float)i * (float)(-(std::log(10000.0) / (double)D)));
+                pe[pos * D + i] = sinf((float)pos * div);
+                pe[pos * D + i + 1] = cosf((float)pos * div);
+            }
+        auto it = P.by_name.find(Dp + "embeddings.make_embedding.pe.pe");
+        if (it != P.by_name.end() && it->second->data) {
+            const mnx_weight_desc* d = it->second;
+            if (d->ndim == 3 && d->shape[0] == c.pe_len && d->shape[1] == 1 && d->shape[2] == D)
+                memcpy(pe.data(), d->data, pe.size() * sizeof(float));   // take the checkpoint's buffer verbatim
+            else
+                P.problems.push_back("shape " + Dp + "embeddings.make_embedding.pe.pe");
+        }
+        dw.pe = P.up32(pe.data(), pe.size());
+    }
+    std::vector<float> memkv_w((size_t)c.dec_layers * 2 * D * D), memkv_b((size_t)c.dec_layers * 2 * D);
+    bool memkv_ok = true;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const std::string p = Dp + "decoder.transformer_layers." + std::to_string(l) + ".";
+        DecLayerW& L = dw.L[l];
+        L.ln1_g = P.f32(p + "layer_norm_1.weight", {D});
+        L.ln1_b = P.f32(p + "layer_norm_1.bias", {D});
+        L.ln2_g = P.f32(p + "layer_norm_2.weight", {D});
+        L.ln2_b = P.f32(p + "layer_norm_2.bias", {D});
+        L.lnf_g = P.f32(p + "feed_forward.layer_norm.weight", {D});
+        L.lnf_b = P.f32(p + "feed_forward.layer_norm.bias", {D});
+        const float *wq = P.host(p + "self_attn.linear_query.weight", {D, D}), *bq = P.host(p + "self_attn.linear_query.bias", {D});
+        const float *wk = P.host(p + "self_attn.linear_keys.weight", {D, D}), *bk = P.host(p + "self_attn.linear_keys.bias", {D});
+        const float *wv = P.host(p + "self_attn.linear_values.weight", {D, D}), *bv = P.host(p + "self_attn.linear_values.bias", {D});
+        if (wq && wk && wv && bq && bk && bv) {
+            std::vector<float> w((size_t)3 * D * D), b((size_t)3 * D);
+            memcpy(&w[0], wq, D * D * 4); memcpy(&w[D * D], wk, D * D * 4); memcpy(&w[2 * D * D], wv, D * D * 4);
+            memcpy(&b[0], bq, D * 4); memcpy(&b[D], bk, D * 4); memcpy(&b[2 * D], bv, D * 4);
+            L.wqkv = P.up32(w.data(), w.size());
+            L.bqkv = P.up32(b.data(), b.size());
+        }
+        L.wo = P.f32(p + "self_attn.final_linear.weight", {D, D});
+        L.bo = P.f32(p + "self_attn.final_linear.bias", {D});
+        L.wq2 = P.f32(p + "context_attn.linear_query.weight", {D, D});
+        L.bq2 = P.f32(p + "context_attn.linear_query.bias", {D});
+        L.wo2 = P.f32(p + "context_attn.final_linear.weight", {D, D});
+        L.bo2 = P.f32(p + "context_attn.final_linear.bias", {D});
+        const float *ck = P.host(p + "context_attn.linear_keys.weight", {D, D}), *cbk = P.host(p + "context_attn.linear_keys.bias", {D});
+        const float *cv = P.host(p + "context_attn.linear_values.weight", {D, D}), *cbv = P.host(p + "context_attn.linear_values.bias", {D});
+        if (ck && cv && cbk && cbv) {
+            memcpy(&memkv_w[(size_t)l * 2 * D * D], ck, D * D * 4);
+            memcpy(&memkv_w[(size_t)l * 2 * D * D + D * D], cv, D * D * 4);
+            memcpy(&memkv_b[(size_t)l * 2 * D], cbk, D * 4);
+            memcpy(&memkv_b[(size_t)l * 2 * D + D], cbv, D * 4);
+        } else {
+            memkv_ok = false;
+        }
+        L.w1 = P.f32(p + "feed_forward.w_1.weight", {FF, D});
+        L.b1 = P.f32(p + "feed_forward.w_1.bias", {FF});
+        L.w2 = P.f32(p + "feed_forward.w_2.weight", {D, FF});
+        L.b2 = P.f32(p + "feed_forward.w_2.bias", {D});
+    }
+    if (memkv_ok) {
+        dw.w_memkv = P.up32(memkv_w.data(), memkv_w.size());
+        dw.b_memkv = P.up32(memkv_b.data(), memkv_b.size());
+    }
+    {
+        const float *w1 = P.host("decoder.edges.mlp.0.weight", {D, 2 * D}), *b1 = P.host("decoder.edges.mlp.0.bias", {D});
+        if (w1 && b1) {
+            std::vector<float> w((size_t)2 * D * D), b((size_t)2 * D, 0.f);
+            for (int64_t n = 0; n < D; ++n) {
+                memcpy(&w[(size_t)n * D], w1 + n * 2 * D, D * 4);              // multiplies h_i
+                memcpy(&w[(size_t)(D + n) * D], w1 + n * 2 * D + D, D * 4);    // multiplies h_j
+                b[D + n] = b1[n];
+            }
+            dw.edge_w1cat = P.up32(w.data(), w.size());
+            dw.edge_b1cat = P.up32(b.data(), b.size());
+        }
+        dw.edge_w2 = P.f32("decoder.edges.mlp.2.weight", {7, D});
+        dw.edge_b2 = P.f32("decoder.edges.mlp.2.bias", {7});
+    }
+    hipFree(P.staging);
+
+    // ---------------- workspace ----------------
+    const size_t MB = (size_t)c.max_batch;
+    const size_t G = c.img_size / c.patch, L0 = G * G, C0 = c.embed_dim;
+    size_t max_qkv = 0, max_h = 0, max_xn = 0;
+    {
+        size_t Ls = L0, Cs = C0;
+        for (int s = 0; s < c.n_stages; ++s) {
+            max_qkv = std::max(max_qkv, Ls * 3 * Cs);
+            max_h = std::max(max_h, Ls * 4 * Cs);
+            max_xn = std::max(max_xn, Ls * Cs);
+            if (s + 1 < c.n_stages) { Ls /= 4; Cs *= 2; }
+        }
+    }
+    h->xa = (float*)P.dalloc(MB * L0 * C0 * 4);
+    h->xb = (float*)P.dalloc(MB * L0 * C0 * 4 / 2);
+    h->xn16 = P.dalloc(MB * max_xn * 2);
+    h->qkv16 = P.dalloc(MB * max_qkv * 2);
+    h->attn16 = P.dalloc(MB * max_xn * 2);
+    h->h16 = P.dalloc(MB * max_h * 2);
+    DecBuffers& db = h->db;
+    db.T = c.max_len; db.S = (int)S; db.max_batch = MAX_ROWS; db.kmax = c.max_atoms;
+    db.st = (DecState*)P.dalloc(sizeof(DecState));
+    db.x = (float*)P.dalloc(MAX_ROWS * D * 4);
+    db.q = (float*)P.dalloc(MAX_ROWS * D * 4);
+    db.ctx = (float*)P.dalloc(MAX_ROWS * D * 4);
+    db.h = (float*)P.dalloc(MAX_ROWS * FF * 4);
+    const size_t cache = (size_t)c.dec_layers * MAX_ROWS * c.dec_heads * c.max_len * 32;
+    db.self_k = (float*)P.dalloc(cache * 4);
+    db.self_v = (float*)P.dalloc(cache * 4);
+    db.memory = (float*)P.dalloc((size_t)MAX_ROWS * S * D * 4);
+    db.mem_kv = (float*)P.dalloc((size_t)MAX_ROWS * S * c.dec_layers * 2 * D * 4);
+    db.edge_g = (float*)P.dalloc((size_t)MAX_ROWS * db.kmax * D * 4);
+    db.edge_uv = (float*)P.dalloc((size_t)MAX_ROWS * db.kmax * 2 * D * 4);
+    db.edge_prob = (float*)P.dalloc((size_t)MAX_ROWS * db.kmax * db.kmax * 8 * 4);
+    h->out_tokens = (int*)P.dalloc((size_t)MAX_ROWS * c.max_len * 4);
+    h->out_logp = (float*)P.dalloc((size_t)MAX_ROWS * c.max_len * 4);
+    h->out_hidden = (float*)P.dalloc((size_t)MAX_ROWS * c.max_len * D * 4);
+    h->out_trace = nullptr;   // allocated lazily on first traced decode (test aid)
+    if (hipHostMalloc((void**)&h->host_flag, 64) != hipSuccess) P.problems.push_back("hipHostMalloc failed");
+
+    if (!P.problems.empty()) {
+        g_create_error = "mnx_create: " + std::to_string(P.problems.size()) + " problem(s):";
+        for (size_t i = 0; i < P.problems.size() && i < 12; ++i) g_create_error += "\n  " + P.problems[i];
+        bool weights_bad = false;
+        for (auto& p : P.problems) weights_bad = weights_bad || p.rfind("missing", 0) == 0 || p.rfind("shape", 0) == 0;
+        mnx_destroy(h);
+        return weights_bad ? MNX_ERR_WEIGHTS : MNX_ERR_HIP;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        g_create_error = "mnx_create: device sync failed";
+        mnx_destroy(h);
+        return MNX_ERR_HIP;
+    }
+    *out = h;
+    return MNX_OK;
+}
+
+int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    h->tap_item = item;
+    h->tap_dst = dst;
+    return MNX_OK;
+}
+
+int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_out, void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!images || !features_out || B < 1) { h->err = "mnx_encode: null/empty argument"; return MNX_ERR_INVALID_ARG; }
+    if (B > h->cfg.max_batch) { h->err = "mnx_encode: B exceeds max_batch"; return MNX_ERR_CAPACITY; }
+    hipStream_t s = (hipStream_t)stream;
+    const mnx_config& c = h->cfg;
+    const int dt = c.compute_dtype;
+    HIPCHK(h, hipSetDevice(h->device));
+    int Hh = c.img_size / c.patch, Ww = Hh, C = c.embed_dim;
+    float* cur = h->xa;
+    float* other = h->xb;
+    int item = 0;
+    auto tap = [&](size_t elems) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (h->tap_item == item && h->tap_dst)
+            e = hipMemcpyAsync(h->tap_dst, cur, elems * sizeof(float), hipMemcpyDeviceToDevice, s);
+        ++item;
+        return e;
+    };
+    HIPCHK(h, launch_patch_embed(images, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta, cur, B, c.img_size, C, s));
+    HIPCHK(h, tap((size_t)B * Hh * Ww * C));
+    for (int si = 0; si < c.n_stages; ++si) {
+        StageW& st = h->stages[si];
+        const int M = B * Hh * Ww;
+        for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
+            const BlockW& w = st.blocks[bi];
+            const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
+            HIPCHK(h, launch_layernorm16(dt, cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C, 1e-5f, s));
+            HIPCHK(h, launch_gemm16(dt, EPI_BIAS_16, h->xn16, w.qkv_w, h->qkv16, w.qkv_b, nullptr, M, 3 * C, C, s));
+            HIPCHK(h, launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s));
+            HIPCHK(h, launch_gemm16(dt, EPI_RESID_F32, h->attn16, w.proj_w, cur, w.proj_b, cur, M, C, C, s));
+            HIPCHK(h, launch_layernorm16(dt, cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C, 1e-5f, s));
+            HIPCHK(h, launch_gemm16(dt, EPI_GELU_16, h->xn16, w.fc1_w, h->h16, w.fc1_b, nullptr, M, 4 * C, C, s));
+            HIPCHK(h, launch_gemm16(dt, EPI_RESID_F32, h->h16, w.fc2_w, cur, w.fc2_b, cur, M, C, 4 * C, s));
+            HIPCHK(h, tap((size_t)M * C));
+        }
+        if (si + 1 < c.n_stages) {
+            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s));
+            HIPCHK(h, launch_gemm16(dt, EPI_BIAS_F32, h->xn16, st.m_w, other, nullptr, nullptr, M / 4, 2 * C, 4 * C, s));
+            std::swap(cur, other);
+            Hh /= 2; Ww /= 2; C *= 2;
+            HIPCHK(h, tap((size_t)B * Hh * Ww * C));
+        }
+    }
+    HIPCHK(h, launch_layernorm16(dt, cur, h->fn_g, h->fn_b, nullptr, features_out, B * Hh * Ww, C, 1e-5f, s));
+    return MNX_OK;
+}
+
+int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
+                      int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, float* token_logp, float* hidden,
+                      float* logits_trace, void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!features || !tokens || !lengths || B < 1) { h->err = "mnx_decode_greedy: null/empty argument"; return MNX_ERR_INVALID_ARG; }
+    if (B > MAX_ROWS || max_len < 1 || max_len > h->cfg.max_len) {
+        h->err = "mnx_decode_greedy: B must be <= 32 and max_len <= cfg.max_len";
+        return MNX_ERR_CAPACITY;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const mnx_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!s) {   // a default-flag stream synchronises implicitly with the null stream on both ends
+        if (!h->own_stream) HIPCHK(h, hipStreamCreate(&h->own_stream));
+        s = h->own_stream;
+    }
+    const int S = h->db.S, D = c.dec_dim;
+    // enc_transform, then the cross-attention K/V of all layers in one SGEMM
+    HIPCHK(h, launch_sgemm_tn(features, h->dw.w_enc, h->dw.b_enc, h->db.memory, B * S, D, h->dw.enc_dim, s));
+    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s));
+    HIPCHK(h, dec_enqueue_init(h->db, chunk_id, B, s));
+    float* trace = nullptr;
+    if (logits_trace) {
+        if (!h->out_trace) {
+            HIPCHK(h, hipMalloc((void**)&h->out_trace, (size_t)c.max_len * MAX_ROWS * c.vocab * 4));
+            h->allocs.push_back(h->out_trace);
+        }
+        trace = h->out_trace;
+    }
+    hipGraphExec_t exec = nullptr;
+    if (h->use_graph) {
+        GraphKey key{B, max_len, stop_on_eos, trace ? 1 : 0};
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            hipError_t e = dec_enqueue_step(h->dw, h->db, B, max_len, stop_on_eos, h->out_tokens, h->out_logp,
+                                            h->out_hidden, trace, s);
+            hipError_t e2 = hipStreamEndCapture(s, &g);
+            if (e != hipSuccess || e2 != hipSuccess) {
+                h->err = std::string("decode step capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+                return MNX_ERR_HIP;
+            }
+            HIPCHK(h, hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            h->graphs[key] = exec;
+        } else {
+            exec = it->second;
+        }
+    }
+    const int poll = 8;
+    for (int t = 0; t < max_len;) {
+        const int n = std::min(poll, max_len - t);
+        for (int i = 0; i < n; ++i) {
+            if (exec) HIPCHK(h, hipGraphLaunch(exec, s));
+            else HIPCHK(h, dec_enqueue_step(h->dw, h->db, B, max_len, stop_on_eos, h->out_tokens, h->out_logp,
+                                            h->out_hidden, trace, s));
+        }
+        t += n;
+        HIPCHK(h, hipMemcpyAsync(h->host_flag, &h->db.st->n_alive, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (*h->host_flag == 0) break;
+    }
+    HIPCHK(h, hipMemcpyAsync(tokens, h->out_tokens, (size_t)B * max_len * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(lengths, h->db.st->len, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    if (token_logp) HIPCHK(h, hipMemcpyAsync(token_logp, h->out_logp, (size_t)B * max_len * 4, hipMemcpyDeviceToDevice, s));
+    if (hidden) HIPCHK(h, hipMemcpyAsync(hidden, h->out_hidden, (size_t)B * max_len * D * 4, hipMemcpyDeviceToDevice, s));
+    if (logits_trace) HIPCHK(h, hipMemcpyAsync(logits_trace, trace, (size_t)max_len * B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return MNX_OK;
+}
+
+int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const int32_t* n_atoms, int32_t B,
+              int32_t kmax, int32_t max_len, uint8_t* edges, double* scores, void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!hidden || !atom_idx || !n_atoms || !edges || B < 1 || kmax < 1 || max_len < 1) {
+        h->err = "mnx_edges: null/empty argument";
+        return MNX_ERR_INVALID_ARG;
+    }
+    if (B > MAX_ROWS || kmax > h->db.kmax) { h->err = "mnx_edges: B <= 32 and kmax <= cfg.max_atoms required"; return MNX_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->device));
+    DecBuffers bf = h->db;
+    HIPCHK(h, edges_enqueue(h->dw, bf, hidden, atom_idx, n_atoms, B, kmax, max_len, edges, scores, (hipStream_t)stream));
+    return MNX_OK;
+}
+
+int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C, const float* bias, int32_t M,
+               int32_t N, int32_t K, void* stream) {
+    if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_gemm16(h->cfg.compute_dtype, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
+                            M, N, K, (hipStream_t)stream));
+    return MNX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+// gemm.hip — 16-bit MFMA GEMM for the Swin "pointwise" Linear layers.
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] )            A, W: bf16 (or fp16), K contiguous in both
+//
+// replaces the nn.Linear calls of the reference encoder (MolNexTR/models/transformers.py:139,141,154,176,
+// timm Mlp fc1/fc2 :218,290, PatchMerging.reduction :307,334) on token-major [B*L, C] activations.
+//
+// Structure (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2(M) x 2(N), each wave 64x64 =
+// 4x4 MFMA 16x16x32 tiles with fp32 accumulators; BK=64; operands staged global -> VGPR -> LDS (16-byte chunks,
+// XOR-swizzled so ds_read_b128 fragment reads are bank-conflict free), double-buffered with the next tile's
+// global loads in flight under the MFMAs. The MFMA is issued "swapped" (A-operand = W rows, B-operand =
+// activation rows) so each lane ends up holding 4 CONSECUTIVE output columns of one row: the epilogue stores
+// 8-byte (16-bit out) or 16-byte (fp32 out) vectors and reads bias/residual as float4.
+#include "common.h"
+#include "kernels.h"
+
+namespace mnx {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+template <typename T>
+struct Stage {
+    typename H16<T>::v8 a[4], w[4];
+};
+
+// byte offset of 16-byte chunk c (0..7) of tile row r in a [128][64] 16-bit LDS tile
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                      void* Cout, const float* __restrict__ bias,
+                                                      const float* resid, int M, int N, int K, int tiles_n,
+                                                      int n_tiles) {
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128][64] x 2 B = 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    // global->register staging coordinates: 4 chunks of A and 4 of W per thread per K-tile
+    const int ld_c = tid & 7, ld_r = tid >> 3;  // chunk column, base row (0..31)
+    const T* a_ptr[4];
+    const T* w_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ra = min(m0 + ld_r + 32 * i, M - 1), rw = min(n0 + ld_r + 32 * i, N - 1);
+        a_ptr[i] = A + (size_t)ra * K + ld_c * 8;
+        w_ptr[i] = W + (size_t)rw * K + ld_c * 8;
+    }
+    const int nk = (K + BK - 1) / BK;
+    Stage<T> st;
+    auto load_g = [&](int kt) {
+        const int k0 = kt * BK;
+        const bool ok = (k0 + ld_c * 8) < K;  // K % 8 == 0: a chunk is all-in or all-out
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v8 z = {};
+            st.a[i] = ok ? *(const v8*)(a_ptr[i] + k0) : z;
+            st.w[i] = ok ? *(const v8*)(w_ptr[i] + k0) : z;
+        }
+    };
+    auto store_s = [&](int buf) {
+        char* ab = smem + buf * (2 * BM * BK * 2);
+        char* wb = ab + BM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = ld_r + 32 * i;
+            *(v8*)(ab + lds_off(r, ld_c)) = st.a[i];
+            *(v8*)(wb + lds_off(r, ld_c)) = st.w[i];
+        }
+    };
+
+    f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_g(0);
+    store_s(0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_g(kt + 1);
+        const char* ab = smem + (kt & 1) * (2 * BM * BK * 2);
+        const char* wb = ab + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const v8*)(ab + lds_off(wm * 64 + t * 16 + fr, ks * 4 + fg));
+                wf[t] = *(const v8*)(wb + lds_off(wn * 64 + t * 16 + fr, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
+        }
+        if (kt + 1 < nk) store_s((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds, per (nt,mt), row m = ..+fr and columns n = ..+fg*4 + {0,1,2,3}
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + fg * 4;
+        if (n >= N) continue;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b4 = *(const f32x4*)(bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + fr;
+            if (m >= M) continue;
+            f32x4 v = acc[nt][mt] + b4;
+            const size_t o = (size_t)m * N + n;
+            if (EPI == EPI_GELU_16) {
+                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+            }
+            if (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16) {
+                v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                *(v4*)((T*)Cout + o) = o4;
+            } else {
+                if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
+                *(f32x4*)((float*)Cout + o) = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
+                           int M, int N, int K, hipStream_t s) {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    dim3 grid(tm * tn), block(256);
+#define MNX_GEMM_CASE(E)                                                                                         \
+    case E:                                                                                                      \
+        hipLaunchKernelGGL((gemm_tn_kernel<T, E>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid, \
+                           M, N, K, tn, tm * tn);                                                                \
+        break;
+    switch (epi) {
+        MNX_GEMM_CASE(EPI_BIAS_16)
+        MNX_GEMM_CASE(EPI_GELU_16)
+        MNX_GEMM_CASE(EPI_RESID_F32)
+        MNX_GEMM_CASE(EPI_BIAS_F32)
+        default: return hipErrorInvalidValue;
+    }
+#undef MNX_GEMM_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                         const float* resid, int M, int N, int K, hipStream_t s) {
+    if ((K & 7) || (N & 3) || M <= 0) return hipErrorInvalidValue;
+    return dtype == MNX_DT_F16 ? launch_t<f16_t>(epi, A, W, C, bias, resid, M, N, K, s)
+                               : launch_t<bf16_t>(epi, A, W, C, bias, resid, M, N, K, s);
+}
+
+}  // namespace mnx

@@ -1,0 +1,218 @@
+"""ctypes binding of libmolnextr_hip.so (include/molnextr_hip.h) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every tensor crosses the C ABI as a raw
+device pointer. There is NO CPU fallback: if the library is missing or no MI355X is present, construction
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import weights as W
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmolnextr_hip.so")
+_lib = None
+
+ABI_VERSION = 1
+SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
+           "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16")
+
+
+class MnxConfig(C.Structure):
+    _fields_ = [("img_size", C.c_int32), ("patch", C.c_int32), ("embed_dim", C.c_int32), ("n_stages", C.c_int32),
+                ("depths", C.c_int32 * 4), ("heads", C.c_int32 * 4), ("window", C.c_int32),
+                ("dec_layers", C.c_int32), ("dec_dim", C.c_int32), ("dec_heads", C.c_int32), ("dec_ff", C.c_int32),
+                ("vocab", C.c_int32), ("sym_offset", C.c_int32), ("coord_bins", C.c_int32), ("pe_len", C.c_int32),
+                ("max_len", C.c_int32), ("max_batch", C.c_int32), ("max_atoms", C.c_int32),
+                ("compute_dtype", C.c_int32)]
+
+
+class MnxWeightDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class MnxError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads libmolnextr_hip.so and declares the prototypes of every symbol of include/molnextr_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C molnextr_amd/csrc`). molnextr_amd has no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.mnx_abi_version.restype = C.c_int
+    lib.mnx_create.restype = C.c_int
+    lib.mnx_create.argtypes = [C.POINTER(MnxConfig), C.POINTER(MnxWeightDesc), i32, i32, C.POINTER(vp)]
+    lib.mnx_destroy.restype = None
+    lib.mnx_destroy.argtypes = [vp]
+    lib.mnx_last_error.restype = C.c_char_p
+    lib.mnx_last_error.argtypes = [vp]
+    lib.mnx_workspace_bytes.restype = C.c_size_t
+    lib.mnx_workspace_bytes.argtypes = [vp]
+    lib.mnx_encode.restype = C.c_int
+    lib.mnx_encode.argtypes = [vp, vp, i32, vp, vp]
+    lib.mnx_set_encoder_tap.restype = C.c_int
+    lib.mnx_set_encoder_tap.argtypes = [vp, i32, vp]
+    lib.mnx_decode_greedy.restype = C.c_int
+    lib.mnx_decode_greedy.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.mnx_edges.restype = C.c_int
+    lib.mnx_edges.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.mnx_gemm16.restype = C.c_int
+    lib.mnx_gemm16.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
+    if lib.mnx_abi_version() != ABI_VERSION:
+        raise ImportError(f"libmolnextr_hip.so ABI {lib.mnx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One engine per GPU. Holds the packed weights and all workspace for `max_batch` images."""
+
+    ROWS_PER_DECODE = 32
+
+    def __init__(self, encoder_state: Dict[str, torch.Tensor], decoder_state: Dict[str, torch.Tensor],
+                 device: int = 0, max_batch: int = 32, enc: W.EncoderDims = W.SWIN_B, dec: W.DecoderDims = W.DEC,
+                 dtype: str = "bf16", max_len: int = 480, max_atoms: int = 160):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise MnxError("no HIP device visible: molnextr_amd needs an MI355X (gfx950); there is no CPU fallback")
+        encoder_state = W.strip_module_prefix(encoder_state)
+        decoder_state = W.strip_module_prefix(decoder_state)
+        W.validate_state(encoder_state, W.encoder_spec(enc), "encoder")
+        W.validate_state(decoder_state, W.decoder_spec(dec), "decoder")
+        ref_idx = W.relative_position_index(enc.window)
+        for k, v in encoder_state.items():
+            if k.endswith("relative_position_index") and not torch.equal(v.cpu().long(), ref_idx):
+                raise ValueError(f"{k} differs from the (dy+11)*23+(dx+11) formula the kernels implement")
+        self.enc, self.dec, self.device = enc, dec, device
+        self.max_batch, self.max_len, self.max_atoms = max_batch, max_len, max_atoms
+        cfg = MnxConfig()
+        cfg.img_size, cfg.patch, cfg.embed_dim, cfg.n_stages = enc.img_size, enc.patch, enc.embed_dim, len(enc.depths)
+        for i, (d, h) in enumerate(zip(enc.depths, enc.heads)):
+            cfg.depths[i], cfg.heads[i] = d, h
+        cfg.window = enc.window
+        cfg.dec_layers, cfg.dec_dim, cfg.dec_heads, cfg.dec_ff = dec.layers, dec.d_model, dec.heads, dec.d_ff
+        cfg.vocab, cfg.sym_offset, cfg.coord_bins, cfg.pe_len = dec.vocab, dec.vocab - 128, 64, dec.pe_len
+        cfg.max_len, cfg.max_batch, cfg.max_atoms = max_len, max_batch, max_atoms
+        cfg.compute_dtype = {"bf16": 0, "fp16": 1}[dtype]
+        self.dtype = dtype
+        keep, descs = [], []
+        for state in (encoder_state, decoder_state):
+            for k, v in state.items():
+                if not v.dtype.is_floating_point:
+                    continue
+                a = np.ascontiguousarray(v.detach().cpu().float().numpy())
+                keep.append(a)
+                d = MnxWeightDesc()
+                d.name = k.encode()
+                d.data = a.ctypes.data
+                d.ndim = a.ndim
+                for i, s in enumerate(a.shape):
+                    d.shape[i] = s
+                descs.append(d)
+        arr = (MnxWeightDesc * len(descs))(*descs)
+        handle = C.c_void_p()
+        rc = self.lib.mnx_create(C.byref(cfg), arr, len(descs), device, C.byref(handle))
+        if rc != 0:
+            raise MnxError(f"mnx_create failed ({rc}): {self.lib.mnx_last_error(None).decode()}")
+        self.h = handle
+        self.n_feat = enc.num_features
+        g = enc.img_size // enc.patch >> (len(enc.depths) - 1)
+        self.n_mem = g * g
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mnx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MnxError(f"{what} failed ({rc}): {self.lib.mnx_last_error(self.h).decode()}")
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mnx_workspace_bytes(self.h))
+
+    # -- Encoder.forward -------------------------------------------------------------------------
+    def encode(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        B = images.shape[0]
+        assert tuple(images.shape[1:]) == (3, self.enc.img_size, self.enc.img_size), images.shape
+        if out is None:
+            out = torch.empty(B, self.n_mem, self.n_feat, device=images.device, dtype=torch.float32)
+        self._check(self.lib.mnx_encode(self.h, _ptr(images), B, _ptr(out), _stream()), "mnx_encode")
+        return out
+
+    def set_tap(self, item: int, dst: Optional[torch.Tensor]):
+        self._check(self.lib.mnx_set_encoder_tap(self.h, item, _ptr(dst)), "mnx_set_encoder_tap")
+
+    # -- TransformerDecoderAR.decode (greedy) ----------------------------------------------------
+    def decode_greedy(self, features: torch.Tensor, chunk_id: Optional[torch.Tensor] = None,
+                      max_len: Optional[int] = None, stop_on_eos: bool = True, want_hidden: bool = True,
+                      want_logp: bool = True, trace_logits: bool = False) -> dict:
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        B = features.shape[0]
+        max_len = self.max_len if max_len is None else max_len
+        dev = features.device
+        tokens = torch.empty(B, max_len, dtype=torch.int32, device=dev)
+        lengths = torch.empty(B, dtype=torch.int32, device=dev)
+        logp = torch.empty(B, max_len, dtype=torch.float32, device=dev) if want_logp else None
+        hidden = torch.empty(B, max_len, self.dec.d_model, dtype=torch.float32, device=dev) if want_hidden else None
+        trace = torch.empty(max_len, B, self.dec.vocab, dtype=torch.float32, device=dev) if trace_logits else None
+        if chunk_id is not None:
+            chunk_id = chunk_id.to(device=dev, dtype=torch.int32).contiguous()
+        rc = self.lib.mnx_decode_greedy(self.h, _ptr(features), B, _ptr(chunk_id), max_len, int(stop_on_eos),
+                                        _ptr(tokens), _ptr(lengths), _ptr(logp), _ptr(hidden), _ptr(trace),
+                                        _stream())
+        self._check(rc, "mnx_decode_greedy")
+        return {"tokens": tokens, "lengths": lengths, "token_logp": logp, "hidden": hidden, "logits": trace}
+
+    # -- GraphPredictor + get_edge_prediction ----------------------------------------------------
+    def edges(self, hidden: torch.Tensor, atom_idx: torch.Tensor, n_atoms: torch.Tensor, want_scores: bool = False):
+        assert hidden.is_cuda and hidden.dtype == torch.float32 and hidden.is_contiguous()
+        B, max_len, _ = hidden.shape
+        atom_idx = atom_idx.to(device=hidden.device, dtype=torch.int32).contiguous()
+        n_atoms = n_atoms.to(device=hidden.device, dtype=torch.int32).contiguous()
+        kmax = atom_idx.shape[1]
+        edges = torch.zeros(B, kmax, kmax, dtype=torch.uint8, device=hidden.device)
+        scores = torch.zeros(B, kmax, kmax, dtype=torch.float64, device=hidden.device) if want_scores else None
+        rc = self.lib.mnx_edges(self.h, _ptr(hidden), _ptr(atom_idx), _ptr(n_atoms), B, kmax, max_len, _ptr(edges),
+                                _ptr(scores), _stream())
+        self._check(rc, "mnx_edges")
+        return edges, scores
+
+    def gemm16(self, epi: int, A: torch.Tensor, Wt: torch.Tensor, Cout: torch.Tensor, bias: Optional[torch.Tensor]):
+        M, K = A.shape
+        N = Wt.shape[0]
+        self._check(self.lib.mnx_gemm16(self.h, epi, _ptr(A), _ptr(Wt), _ptr(Cout), _ptr(bias), M, N, K, _stream()),
+                    "mnx_gemm16")
+        return Cout
