@@ -133,6 +133,13 @@ int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const
 int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C, const float* bias, int32_t M,
                int32_t N, int32_t K, void* stream);
 
+/* Measurement aid for bench.py: while enabled, mnx_encode brackets every MFMA GEMM launch with a pair of HIP
+ * events recorded on the caller's stream. mnx_profile_read synchronises, returns the totals accumulated since
+ * the last read (summed event-to-event milliseconds, algorithmic FLOP = 2*M*N*K per launch, launch count) and
+ * resets them. */
+int mnx_profile_enable(mnx_engine* h, int32_t enable);
+int mnx_profile_read(mnx_engine* h, double* gemm_ms, double* gemm_flop, int64_t* gemm_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,60 +97,96 @@ template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[32 * XS];
     __shared__ __attribute__((aligned(16))) float ws[TN * XS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_tok[32], s_rank[32];
+    const int tid = threadIdx.x;
     const int r = tid & 31, c = tid >> 5;
     const int n0 = blockIdx.x * TN;
     const int B = a.B;
-    float acc = 0.f;
-    for (int k0 = 0; k0 < a.K; k0 += 256) {
-        // ---- stage the input slab [B, 256] ---------------------------------------------------
-        if (PRO == 2) {
-            // x0[r] = E[tok_r] * sqrt(256) + pe[row_r]; row_r = rank of r among the still-alive rows of its
-            // reference batch chunk — the reference adds a sequence-first PE table to a batch-first tensor and
-            // compacts finished rows out of the batch (components.py:290, embedding.py:52-59,
-            // greedy_search.py:182-190).
-            for (int rr = wave; rr < B; rr += 4) {
-                const int tok = a.st->prev_tok[rr];
-                int rank = 0;
-                for (int q = 0; q < rr; ++q) rank += (a.st->alive[q] != 0 && a.st->chunk[q] == a.st->chunk[rr]);
-                const f32x4 e = *(const f32x4*)(a.emb + (size_t)tok * 256 + lane * 4);
-                const f32x4 p = *(const f32x4*)(a.pe + (size_t)rank * 256 + lane * 4);
-                const f32x4 v = e * 16.0f + p;
-                *(f32x4*)(xs + rr * XS + lane * 4) = v;
-                if (blockIdx.x == 0) *(f32x4*)(a.x_write + rr * 256 + lane * 4) = v;
+    // LayerNorm / embedding thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
+    const int lrow = tid >> 3, part = tid & 7;
+    if (PRO == 2) {
+        // PE row of every slot = rank among the still-alive rows of its reference batch chunk: the reference
+        // adds a sequence-first PE table to a batch-first tensor and compacts finished rows out of the batch
+        // (components.py:290, embedding.py:52-59, greedy_search.py:182-190).
+        if (tid < 32) {
+            const int alive = tid < B ? a.st->alive[tid] : 0;
+            const int chunk = tid < B ? a.st->chunk[tid] : -1;
+            int rank = 0;
+            for (int q = 0; q < 32; ++q) {
+                const int aq = __shfl(alive, q, 64), cq = __shfl(chunk, q, 64);
+                rank += (q < tid && aq != 0 && cq == chunk);
             }
-        } else {
-            for (int i = tid; i < B * 64; i += 256) {
-                const int rr = i >> 6, q = i & 63;
-                *(f32x4*)(xs + rr * XS + q * 4) = *(const f32x4*)(a.in + (size_t)rr * a.K + k0 + q * 4);
-            }
-        }
-        for (int i = tid; i < TN * 64; i += 256) {
-            const int nn = i >> 6, q = i & 63;
-            *(f32x4*)(ws + nn * XS + q * 4) = *(const f32x4*)(a.W + (size_t)(n0 + nn) * a.K + k0 + q * 4);
+            s_rank[tid] = rank;
+            s_tok[tid] = tid < B ? a.st->prev_tok[tid] : 0;
         }
         __syncthreads();
-        if (PRO != 0) {  // LayerNorm in place, one wave per row, 4 channels per lane (K == 256)
-            const f32x4 g = *(const f32x4*)(a.gamma + lane * 4), bt = *(const f32x4*)(a.beta + lane * 4);
-            for (int rr = wave; rr < B; rr += 4) {
-                f32x4 v = *(const f32x4*)(xs + rr * XS + lane * 4);
-                const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
-                v -= mean;
-                const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
-                *(f32x4*)(xs + rr * XS + lane * 4) = v * rsqrtf(var + 1e-6f) * g + bt;
-            }
-            __syncthreads();
+    }
+    float acc = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 256) {
+        // ---- stage the input slab [B, 256] and the weight tile [8, 256]: all loads first, then LDS stores ----
+        f32x4 xv[8], wv[2];
+        if (PRO == 2) {
+            // x0[r] = E[tok_r] * sqrt(256) + pe[rank_r]
+            const float* e = a.emb + (size_t)s_tok[lrow] * 256 + part * 4;
+            const float* p = a.pe + (size_t)s_rank[lrow] * 256 + part * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xv[j] = lrow < B ? *(const f32x4*)(e + 32 * j) * 16.0f + *(const f32x4*)(p + 32 * j)
+                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            const float* src = a.in + (size_t)lrow * a.K + k0 + part * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xv[j] = lrow < B ? *(const f32x4*)(src + 32 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j, nn = i >> 6, q = i & 63;
+            wv[j] = *(const f32x4*)(a.W + (size_t)(n0 + nn) * a.K + k0 + q * 4);
+        }
+        if (PRO == 2 && blockIdx.x == 0 && lrow < B) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(f32x4*)(a.x_write + lrow * 256 + part * 4 + 32 * j) = xv[j];
+        }
+        if (PRO != 0) {  // LayerNorm in registers: 8 lanes per row, two-pass (K == 256)
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += xv[j][0] + xv[j][1] + xv[j][2] + xv[j][3];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            const float mean = s * (1.0f / 256.0f);
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xv[j] -= mean;
+                sq += xv[j][0] * xv[j][0] + xv[j][1] * xv[j][1] + xv[j][2] * xv[j][2] + xv[j][3] * xv[j][3];
+            }
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xv[j] = xv[j] * rstd * *(const f32x4*)(a.gamma + part * 4 + 32 * j) +
+                        *(const f32x4*)(a.beta + part * 4 + 32 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(f32x4*)(xs + lrow * XS + part * 4 + 32 * j) = xv[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j, nn = i >> 6, q = i & 63;
+            *(f32x4*)(ws + nn * XS + q * 4) = wv[j];
+        }
+        __syncthreads();
         const float* xr = xs + r * XS;
         const float* wr = ws + c * XS;
-#pragma unroll 8
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 16
         for (int k = 0; k < 256; k += 4) {
-            const f32x4 xv = *(const f32x4*)(xr + k), wv = *(const f32x4*)(wr + k);
-            acc = fmaf(xv[0], wv[0], acc);
-            acc = fmaf(xv[1], wv[1], acc);
-            acc = fmaf(xv[2], wv[2], acc);
-            acc = fmaf(xv[3], wv[3], acc);
+            const f32x4 x4 = *(const f32x4*)(xr + k), w4 = *(const f32x4*)(wr + k);
+            a0 = fmaf(x4[0], w4[0], a0);
+            a1 = fmaf(x4[1], w4[1], a1);
+            a2 = fmaf(x4[2], w4[2], a2);
+            a3 = fmaf(x4[3], w4[3], a3);
         }
+        acc += (a0 + a1) + (a2 + a3);
         __syncthreads();
     }
     if (r >= B) return;
@@ -207,13 +243,16 @@ __global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
         float s = -3.0e38f;
         if (key < nkeys) {
             const float* kp = Kb + (size_t)key * a.kstride;
-            s = 0.f;
+            f32x4 kv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(kp + i * 4);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const f32x4 kv = *(const f32x4*)(kp + i * 4);
-                s = fmaf(q[i][0], kv[0], s); s = fmaf(q[i][1], kv[1], s);
-                s = fmaf(q[i][2], kv[2], s); s = fmaf(q[i][3], kv[3], s);
+                s0 = fmaf(q[i][0], kv[i][0], s0); s1 = fmaf(q[i][1], kv[i][1], s1);
+                s2 = fmaf(q[i][2], kv[i][2], s2); s3 = fmaf(q[i][3], kv[i][3], s3);
             }
+            s = (s0 + s1) + (s2 + s3);
         }
         sc[j] = s;
         mx = fmaxf(mx, s);
@@ -223,19 +262,29 @@ __global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int key = lane + j * 64;
-        if (key < nkeys) {
-            const float p = expf(sc[j] - mx);
-            ps[key] = p;
-            sum += p;
-        }
+        const float p = key < nkeys ? expf(sc[j] - mx) : 0.f;
+        ps[key] = p;
+        sum += p;
     }
     sum = wave_sum(sum);
     __syncthreads();
-    const int d = lane & 31, half = lane >> 5;
-    float o = 0.f;
-    for (int key = half; key < nkeys; key += 2) o = fmaf(ps[key], Vb[(size_t)key * a.kstride + d], o);
-    o += __shfl_xor(o, 32, 64);
-    if (lane < 32) a.ctx[r * 256 + hd * 32 + d] = o / sum;
+    // P.V: lane = (key group kg = lane>>3, channel quad dq = lane&7); 8 keys per wave-load, independent loads
+    const int kg = lane >> 3, dq = lane & 7;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    const int nk8 = (nkeys + 7) & ~7;
+#pragma unroll 4
+    for (int key = kg; key < nk8; key += 8) {
+        const int kk = key < nkeys ? key : nkeys - 1;
+        const f32x4 v = *(const f32x4*)(Vb + (size_t)kk * a.kstride + dq * 4);
+        o += v * ps[key];       // ps[key] == 0 for key >= nkeys
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] += __shfl_xor(o[i], 8, 64);
+        o[i] += __shfl_xor(o[i], 16, 64);
+        o[i] += __shfl_xor(o[i], 32, 64);
+    }
+    if (lane < 8) *(f32x4*)(a.ctx + r * 256 + hd * 32 + dq * 4) = o * (1.0f / sum);
 }
 
 // =============================================================================================
@@ -279,9 +328,15 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     float logit = -3.0e38f;
     if (valid) {
         float s = 0.f;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-        for (int k = 0; k < 256; ++k) s = fmaf(hv[k], a.wout_t[k * a.VP + tid], s);
-        logit = s + a.bout[tid];
+        for (int k = 0; k < 256; k += 4) {     // 32 independent coalesced loads in flight per unrolled body
+            s = fmaf(hv[k], a.wout_t[k * a.VP + tid], s);
+            s1 = fmaf(hv[k + 1], a.wout_t[(k + 1) * a.VP + tid], s1);
+            s2 = fmaf(hv[k + 2], a.wout_t[(k + 2) * a.VP + tid], s2);
+            s3 = fmaf(hv[k + 3], a.wout_t[(k + 3) * a.VP + tid], s3);
+        }
+        logit = (s + s1) + (s2 + s3) + a.bout[tid];
         if (a.logits_trace && t < a.max_len) a.logits_trace[((size_t)t * a.B + r) * a.V + tid] = logit;
     }
     // log_softmax

@@ -63,6 +63,11 @@ struct mnx_engine {
     std::map<GraphKey, hipGraphExec_t> graphs;
     bool use_graph = true;
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
+    // profiling (bench aid)
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; double flop; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
 };
 
 namespace {
@@ -192,6 +197,7 @@ void mnx_destroy(mnx_engine* h) {
     hipSetDevice(h->device);
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
+    for (auto& ev : h->ev_pool) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (void* p : h->allocs) hipFree(p);
     if (h->host_flag) hipHostFree(h->host_flag);
     delete h;
@@ -485,6 +491,23 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         ++item;
         return e;
     };
+    auto gemm = [&](int epi, const void* A, const void* Wt, void* Cc, const float* bias, const float* resid, int M,
+                    int N, int K) -> hipError_t {
+        if (!h->profiling) return launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s);
+        if (h->ev_used == h->ev_pool.size()) {
+            mnx_engine::Ev ev{};
+            hipError_t e1 = hipEventCreate(&ev.a), e2 = hipEventCreate(&ev.b);
+            if (e1 != hipSuccess || e2 != hipSuccess) return e1 != hipSuccess ? e1 : e2;
+            h->ev_pool.push_back(ev);
+        }
+        mnx_engine::Ev& ev = h->ev_pool[h->ev_used++];
+        ev.flop = 2.0 * (double)M * (double)N * (double)K;
+        hipError_t e0 = hipEventRecord(ev.a, s);
+        if (e0 != hipSuccess) return e0;
+        e0 = launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s);
+        if (e0 != hipSuccess) return e0;
+        return hipEventRecord(ev.b, s);
+    };
     HIPCHK(h, launch_patch_embed(images, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta, cur, B, c.img_size, C, s));
     HIPCHK(h, tap((size_t)B * Hh * Ww * C));
     for (int si = 0; si < c.n_stages; ++si) {
@@ -494,17 +517,17 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
             const BlockW& w = st.blocks[bi];
             const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
             HIPCHK(h, launch_layernorm16(dt, cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C, 1e-5f, s));
-            HIPCHK(h, launch_gemm16(dt, EPI_BIAS_16, h->xn16, w.qkv_w, h->qkv16, w.qkv_b, nullptr, M, 3 * C, C, s));
+            HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, w.qkv_w, h->qkv16, w.qkv_b, nullptr, M, 3 * C, C));
             HIPCHK(h, launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s));
-            HIPCHK(h, launch_gemm16(dt, EPI_RESID_F32, h->attn16, w.proj_w, cur, w.proj_b, cur, M, C, C, s));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, w.proj_w, cur, w.proj_b, cur, M, C, C));
             HIPCHK(h, launch_layernorm16(dt, cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C, 1e-5f, s));
-            HIPCHK(h, launch_gemm16(dt, EPI_GELU_16, h->xn16, w.fc1_w, h->h16, w.fc1_b, nullptr, M, 4 * C, C, s));
-            HIPCHK(h, launch_gemm16(dt, EPI_RESID_F32, h->h16, w.fc2_w, cur, w.fc2_b, cur, M, C, 4 * C, s));
+            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, w.fc1_w, h->h16, w.fc1_b, nullptr, M, 4 * C, C));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->h16, w.fc2_w, cur, w.fc2_b, cur, M, C, 4 * C));
             HIPCHK(h, tap((size_t)M * C));
         }
         if (si + 1 < c.n_stages) {
             HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s));
-            HIPCHK(h, launch_gemm16(dt, EPI_BIAS_F32, h->xn16, st.m_w, other, nullptr, nullptr, M / 4, 2 * C, 4 * C, s));
+            HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, st.m_w, other, nullptr, nullptr, M / 4, 2 * C, 4 * C));
             std::swap(cur, other);
             Hh /= 2; Ww /= 2; C *= 2;
             HIPCHK(h, tap((size_t)B * Hh * Ww * C));
@@ -597,6 +620,30 @@ int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const
     HIPCHK(h, hipSetDevice(h->device));
     DecBuffers bf = h->db;
     HIPCHK(h, edges_enqueue(h->dw, bf, hidden, atom_idx, n_atoms, B, kmax, max_len, edges, scores, (hipStream_t)stream));
+    return MNX_OK;
+}
+
+int mnx_profile_enable(mnx_engine* h, int32_t enable) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    h->profiling = enable != 0;
+    return MNX_OK;
+}
+
+int mnx_profile_read(mnx_engine* h, double* gemm_ms, double* gemm_flop, int64_t* gemm_launches) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    double ms = 0.0, flop = 0.0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float t = 0.f;
+        HIPCHK(h, hipEventSynchronize(h->ev_pool[i].b));
+        HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[i].a, h->ev_pool[i].b));
+        ms += t;
+        flop += h->ev_pool[i].flop;
+    }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flop) *gemm_flop = flop;
+    if (gemm_launches) *gemm_launches = (int64_t)h->ev_used;
+    h->ev_used = 0;
     return MNX_OK;
 }
 

@@ -20,7 +20,8 @@ _lib = None
 
 ABI_VERSION = 1
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
-           "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16")
+           "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
+           "mnx_profile_read")
 
 
 class MnxConfig(C.Structure):
@@ -74,6 +75,10 @@ def load_library():
     lib.mnx_edges.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.mnx_gemm16.restype = C.c_int
     lib.mnx_gemm16.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mnx_profile_enable.restype = C.c_int
+    lib.mnx_profile_enable.argtypes = [vp, i32]
+    lib.mnx_profile_read.restype = C.c_int
+    lib.mnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if lib.mnx_abi_version() != ABI_VERSION:
         raise ImportError(f"libmolnextr_hip.so ABI {lib.mnx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
     _lib = lib
@@ -209,6 +214,15 @@ class Engine:
                                 _ptr(scores), _stream())
         self._check(rc, "mnx_edges")
         return edges, scores
+
+    def profile(self, enable: bool):
+        self._check(self.lib.mnx_profile_enable(self.h, int(enable)), "mnx_profile_enable")
+
+    def profile_read(self):
+        """(gemm_ms, gemm_flop, launches) accumulated by HIP events since the last read."""
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.mnx_profile_read(self.h, C.byref(ms), C.byref(fl), C.byref(n)), "mnx_profile_read")
+        return ms.value, fl.value, n.value
 
     def gemm16(self, epi: int, A: torch.Tensor, Wt: torch.Tensor, Cout: torch.Tensor, bias: Optional[torch.Tensor]):
         M, K = A.shape

@@ -1,0 +1,165 @@
+"""Model facade: mirrors the reference's `molnextr` class and `Decoder.decode` on top of the HIP engine.
+
+  decode_batch(...)        <-> Decoder.decode                       reference MolNexTR/components.py:443-492
+  molnextr.predict_images  <-> molnextr.predict_images              reference MolNexTR/model.py:97-146
+  molnextr.predict_image / predict_image_files / predict_final_results   reference MolNexTR/model.py:148-196
+
+Same method names, argument meaning and output dict keys. Everything between "normalised image batch" and "token
+ids / hidden states / bond matrix" runs in libmolnextr_hip.so; tokens are turned into symbols / coordinates /
+atom positions on the host (tokenizer.py), as in the reference. No CPU fallback exists for the device part.
+"""
+from __future__ import annotations
+
+import argparse
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import weights as W
+from .engine import Engine
+from .preprocess import load_image_rgb, transform_image
+from .tokenizer import get_tokenizer
+
+BOND_TYPES = ["", "single", "double", "triple", "aromatic", "solid wedge", "dashed wedge"]  # reference model.py:30
+ROWS = Engine.ROWS_PER_DECODE
+
+
+def decode_batch(engine: Engine, features: torch.Tensor, tokenizer=None, ref_batch_size: Optional[int] = None,
+                 compute_confidence: bool = False, max_len: Optional[int] = None) -> List[dict]:
+    """Decoder.decode for formats ['chartok_coords', 'edges'] (reference components.py:443-492).
+
+    features [B,144,1024] on the GPU. `ref_batch_size`: rows are numbered as if the reference had decoded them in
+    consecutive batches of this size (its positional encoding is indexed by the row inside the batch and finished
+    rows are compacted away, so results depend on the batch composition); None = one batch of B (B <= 32) or
+    batches of 32. Returns one dict per image: {'chartok_coords': {smiles, symbols, coords, indices[, atom_scores]},
+    'edges': [[...]] [, 'edge_scores', 'overall_score']}.
+    """
+    tok = (tokenizer or get_tokenizer())["chartok_coords"]
+    B = features.shape[0]
+    rbs = ref_batch_size or ROWS
+    if rbs > ROWS:
+        raise ValueError(f"reference batches larger than {ROWS} rows are not supported by one engine call")
+    group = (ROWS // rbs) * rbs          # rows per engine call: whole reference batches only
+    preds: List[dict] = []
+    for g0 in range(0, B, group):
+        feats = features[g0:g0 + group].contiguous()
+        n = feats.shape[0]
+        chunk = torch.arange(n, dtype=torch.int32) // rbs
+        out = engine.decode_greedy(feats, chunk_id=chunk, max_len=max_len, want_logp=True)
+        lens = out["lengths"].cpu().numpy()
+        toks = out["tokens"].cpu().numpy()
+        logp = out["token_logp"].cpu().numpy() if compute_confidence else None
+        rows = [tok.sequence_to_smiles(toks[b, :lens[b]].tolist()) for b in range(n)]
+        kmax = engine.max_atoms
+        n_atoms = np.array([len(r["indices"]) for r in rows], dtype=np.int32)
+        if n_atoms.max(initial=0) > kmax:
+            raise RuntimeError(f"{int(n_atoms.max())} atoms exceed the engine capacity max_atoms={kmax}")
+        atom_idx = np.zeros((n, kmax), dtype=np.int32)
+        for b, r in enumerate(rows):
+            atom_idx[b, :n_atoms[b]] = r["indices"]
+        edges, scores = engine.edges(out["hidden"], torch.from_numpy(atom_idx), torch.from_numpy(n_atoms),
+                                     want_scores=compute_confidence)
+        edges = edges.cpu().numpy()
+        scores = scores.cpu().numpy() if scores is not None else None
+        for b, r in enumerate(rows):
+            k = int(n_atoms[b])
+            pred = {"chartok_coords": r, "edges": edges[b, :k, :k].astype(int).tolist()}
+            if compute_confidence:   # reference components.py:456-469, 485-491
+                ts = np.exp(logp[b, :lens[b]].astype(np.float64))
+                idx = np.array(r["indices"]) - 3
+                r["atom_scores"] = [float(np.prod(ts[i - len(s) + 1:i + 1]) ** (1 / len(s)))
+                                    for s, i in zip(r["symbols"], idx)]
+                avg = float(np.exp(np.mean(logp[b, :lens[b]].astype(np.float64))))
+                es = scores[b, :k, :k]
+                pred["edge_scores"] = es.tolist()
+                pred["overall_score"] = avg * float(np.sqrt(np.prod(es)))
+            preds.append(pred)
+    return preds
+
+
+class molnextr:
+    """Main interface (reference MolNexTR/model.py:33-196).
+
+    model_path: a checkpoint in the reference's format ({'encoder','decoder','args'}); or None / 'synthetic' for
+    the deterministic synthetic checkpoint (no pretrained weights exist offline).
+    device: torch.device('cuda', i) — an MI355X is required."""
+
+    def __init__(self, model_path=None, device=None, max_batch: int = 32, dtype: str = "bf16"):
+        if model_path in (None, "synthetic"):
+            states = W.synthetic_checkpoint(0)
+        else:
+            states = torch.load(model_path, map_location=torch.device("cpu"))
+        args = self._get_args(states.get("args"))
+        if device is None:
+            device = torch.device("cuda", 0)
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("molnextr_amd runs the model on an MI355X only (no CPU path); pass device='cuda:N'")
+        self.device = device
+        self.args = args
+        self.tokenizer = get_tokenizer(args)
+        self.engine = Engine(states["encoder"], states["decoder"], device=device.index or 0, max_batch=max_batch,
+                             dtype=dtype)
+        self.input_size = args.input_size
+
+    @staticmethod
+    def _get_args(args_states=None):
+        """Inference defaults of the reference (model.py:50-81) overridden by the checkpoint's saved args."""
+        a = argparse.Namespace(encoder="swin_base", decoder="transformer", enc_pos_emb=False, dec_num_layers=6,
+                               dec_hidden_size=256, dec_attn_heads=8, continuous_coords=False,
+                               compute_confidence=False, input_size=384, vocab_file=None, coord_bins=64, sep_xy=True,
+                               formats=["chartok_coords", "edges"])
+        for k, v in (args_states or {}).items():
+            setattr(a, k, v)
+        if a.encoder != "swin_base" or a.input_size != 384 or a.continuous_coords:
+            raise NotImplementedError("engine is built for the swin_base / 384 / discrete-coordinate configuration")
+        return a
+
+    def predict_images(self, input_images: List, return_atoms_bonds=False, return_confidence=False, batch_size=16):
+        preds: List[dict] = []
+        step = max(self.engine.max_batch // batch_size, 1) * batch_size
+        for i in range(0, len(input_images), step):
+            imgs = [transform_image(im, self.input_size) for im in input_images[i:i + step]]
+            x = torch.from_numpy(np.stack(imgs)).to(self.device)
+            feats = self.engine.encode(x)
+            preds += decode_batch(self.engine, feats, self.tokenizer, ref_batch_size=min(batch_size, 32),
+                                  compute_confidence=return_confidence)
+        from .chem import convert_graph_to_smiles
+        smiles_list, molblock_list, _ = convert_graph_to_smiles(
+            [p["chartok_coords"]["coords"] for p in preds], [p["chartok_coords"]["symbols"] for p in preds],
+            [p["edges"] for p in preds], images=input_images)
+        outputs = []
+        for smiles, molfile, pred in zip(smiles_list, molblock_list, preds):
+            d = {"predicted_smiles": smiles, "predicted_molfile": molfile}
+            if return_atoms_bonds:
+                c = pred["chartok_coords"]
+                atoms = []
+                for i, (sym, xy) in enumerate(zip(c["symbols"], c["coords"])):
+                    a = {"atom_number": f"{i}", "atom_symbol": sym, "coords": (round(xy[0], 3), round(xy[1], 3))}
+                    if return_confidence:
+                        a["confidence"] = c["atom_scores"][i]
+                    atoms.append(a)
+                d["atom_sets"] = atoms
+                bonds = []
+                k = len(c["symbols"])
+                for i in range(k - 1):
+                    for j in range(i + 1, k):
+                        t = pred["edges"][i][j]
+                        if t != 0:
+                            bd = {"atom_number": f"{i}", "bond_type": BOND_TYPES[t], "endpoints": (i, j)}
+                            if return_confidence:
+                                bd["confidence"] = pred["edge_scores"][i][j]
+                            bonds.append(bd)
+                d["bond_sets"] = bonds
+            outputs.append(d)
+        return outputs
+
+    def predict_image(self, image, return_atoms_bonds=False, return_confidence=False):
+        return self.predict_images([image], return_atoms_bonds, return_confidence)[0]
+
+    def predict_image_files(self, image_files: List, return_atoms_bonds=False, return_confidence=False):
+        return self.predict_images([load_image_rgb(p) for p in image_files], return_atoms_bonds, return_confidence)
+
+    def predict_final_results(self, image_file: str, return_atoms_bonds=False, return_confidence=False):
+        return self.predict_image_files([image_file], return_atoms_bonds, return_confidence)[0]

@@ -261,8 +261,9 @@ def _shape_decode_dynamics(d: "OrderedDict[str, torch.Tensor]", dec: DecoderDims
          y -> atom letter | link char | EOS, link -> atom letter;
       3. layer-0 self-attention head 0 attends to the SOS key with weight 50/(50+t), writing an "age"
          feature into residual dim 6 that the EOS logit reads with a negative weight, so EOS becomes
-         likely after ~30..300 tokens, at a different step for every row/image.
-    Measured on the CPU oracle (seed 0, 16 synthetic images): decoded lengths 16..480, mean ~129 tokens, 3..152 atoms."""
+         likely after ~30..330 tokens, at a different step for every row/image.
+    Measured on the CPU oracle (seed 0, 16 synthetic images): decoded lengths 33..330 tokens, mean 135; 32 atoms on
+    average — the shape of a real molecule workload (the reference caps sequences at 480)."""
     if dec.vocab != 229 or dec.d_model < 64:
         return
     import json
@@ -270,7 +271,7 @@ def _shape_decode_dynamics(d: "OrderedDict[str, torch.Tensor]", dec: DecoderDims
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "vocab", "vocab_chars.json")) as f:
         stoi = json.load(f)
     P = "decoder.chartok_coords."
-    V, m, p, eos_pref, K, half = dec.vocab, 0.25, 4.0, 1.1, 3.0, 50.0
+    V, m, p, eos_pref, K, half, age0 = dec.vocab, 0.25, 4.0, 2.8, 6.0, 50.0, 24.0
     letters = [i for s, i in stoi.items() if i >= 5 and s.isalpha()]
     upper = [stoi[c] for c in "CNOSFPBIH"]
     link = [stoi[c] for c in "()=#123"]
@@ -306,7 +307,7 @@ def _shape_decode_dynamics(d: "OrderedDict[str, torch.Tensor]", dec: DecoderDims
     sos_feat = 16.0 * m / 1.2
     d[L0 + "linear_keys.weight"][0, 0] = 4.0 / sos_feat
     d[L0 + "linear_query.bias"][0] = math.log(half) * math.sqrt(dh) / 4.0
-    d[L0 + "linear_values.weight"][0, 0] = 8.0 / sos_feat
+    d[L0 + "linear_values.weight"][0, 0] = age0 / sos_feat
     d[L0 + "final_linear.weight"][:, 0:dh] = 0
     d[L0 + "final_linear.weight"][6, 0] = 1.0
 
