@@ -199,7 +199,8 @@ def test_bond_head_ragged_batch_and_empty(eng, dev, synth_ckpt):
     ks = [0, 1, 57, 159]
     ai = torch.zeros(4, 160, dtype=torch.int32)
     for b, k in enumerate(ks):
-        ai[b, :k] = torch.sort((W.hash_normal(f"ragged_idx{b}", (k,), 1.0).abs() * 120).long() % 480)[0].int()
+        order = torch.argsort(W.hash_normal(f"ragged_idx{b}", (480,), 1.0))      # distinct positions: no exact ties
+        ai[b, :k] = torch.sort(order[:k])[0].int()
     e, _ = eng.edges(hidden.to(dev), ai.to(dev), torch.tensor(ks, dtype=torch.int32))
     e = e.cpu().numpy()
     for b, k in enumerate(ks):
