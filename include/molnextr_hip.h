@@ -127,6 +127,33 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
 int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const int32_t* n_atoms, int32_t B,
               int32_t kmax, int32_t max_len, uint8_t* edges, double* scores, void* stream);
 
+/* Token classes for the on-device atom-position scan used by mnx_predict (the 'indices' that
+ * CharTokenizer.sequence_to_smiles derives, MolNexTR/tokenization.py:464-515). flags[id]: bit0 = is_symbol(id),
+ * bit1 = is_atom(id) for id < n (= number of vocabulary symbols); the ids of '[' ']' 'C' 'l' 'B' 'r'. */
+int mnx_set_token_classes(mnx_engine* h, const uint8_t* flags, int32_t n, int32_t lbracket, int32_t rbracket,
+                          int32_t id_C, int32_t id_l, int32_t id_B, int32_t id_r);
+
+/* The atom-position scan on its own (test aid and building block of mnx_predict): tokens device int32 [n,T],
+ * lengths device int32 [n] -> atom_idx device int32 [n,kmax], n_atoms device int32 [n]. */
+int mnx_atom_scan(mnx_engine* h, const int32_t* tokens, const int32_t* lengths, int32_t n, int32_t T, int32_t kmax,
+                  int32_t* atom_idx, int32_t* n_atoms, void* stream);
+
+/* The whole hot path for a list of images, with continuous batching: replaces the body of the chunk loop of
+ * `molnextr.predict_images` (MolNexTR/model.py:102-109: encoder + decoder.decode for every chunk) up to, but not
+ * including, the host-side detokenisation to symbols / coordinates.
+ *   images    device fp32 [n_img,3,S,S]
+ *   ref_batch images are decoded as consecutive reference batches of this many rows (<= 32): every batch is one
+ *             positional-encoding numbering, exactly as if the reference had been called with this batch_size
+ * Up to 256 sequences (8 reference batches) are resident on the GPU at once; every decode tick advances all of
+ * them by one token, finished batches are retired (atom positions + bond head run on device) and the freed rows are
+ * refilled with the next batch while the encoder of the following batch runs on a second stream.
+ *   tokens    device int32 [n_img,max_len]; lengths device int32 [n_img]
+ *   n_atoms   device int32 [n_img]; atom_idx device int32 [n_img,kmax]; edges device uint8 [n_img,kmax,kmax]
+ * Synchronous with respect to its outputs. */
+int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t max_len,
+                int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx, uint8_t* edges,
+                int32_t kmax, void* stream);
+
 /* Kernel-level timing aid for bench.py: runs the 16-bit MFMA GEMM of the encoder on caller buffers.
  * C[M,N] = A[M,K] . W[N,K]^T + bias, A/W 16-bit device, epi: 0 bias->16-bit, 1 bias+GELU->16-bit,
  * 2 bias+residual(fp32, in place in C), 3 bias->fp32. */

@@ -1,22 +1,33 @@
-// dec_types.h — decoder-side device structures shared by decoder.hip and engine.cpp (internal).
+// dec_types.h — decoder-side device structures shared by decoder.hip and engine.hip (internal).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mnx {
 
-constexpr int MAX_ROWS = 32;       // rows per decode call (= the reference's natural batch unit)
+constexpr int MAX_SLOTS = 256;     // decode rows resident on the GPU at once (8 reference batches of 32)
+constexpr int ROW_TILE = 32;       // rows per workgroup of the skinny linears; also the max reference batch
 constexpr int MAX_DEC_LAYERS = 8;
+constexpr int MAX_CHUNKS = 64;     // reference batches in flight (slots of one batch may be scattered)
 
-// Per-call decode state, lives in device memory and is advanced by the step graph itself.
+// Decode state of every slot; lives in device memory and is advanced by the tick graph itself.
+// A "slot" is one sequence being decoded. Slots of one reference batch ("chunk") share a positional-encoding
+// numbering: slot s gets pe[rank(s)], rank = number of alive slots of the same chunk with a smaller row index
+// (the reference adds a sequence-first PE to a batch-first tensor and compacts finished rows out of the batch).
 struct DecState {
-    int step;                 // index of the step being computed
-    int ticket;               // arrival counter of dec_head_kernel workgroups
-    int n_alive;
-    int alive[MAX_ROWS];
-    int prev_tok[MAX_ROWS];
-    int len[MAX_ROWS];
-    int chunk[MAX_ROWS];      // reference-batch id of each row (rows of one id share a PE numbering)
+    int tick;
+    int n_active;                  // alive slots (polled by the host)
+    int chunk_alive[MAX_CHUNKS];   // alive slots per chunk tag (polled by the host)
+    int alive[MAX_SLOTS];
+    int t[MAX_SLOTS];              // next position to decode (= tokens emitted so far)
+    int prev_tok[MAX_SLOTS];
+    int len[MAX_SLOTS];
+    int chunk[MAX_SLOTS];          // chunk tag 0..MAX_CHUNKS-1
+    int rowc[MAX_SLOTS];           // row index inside the reference batch
+    int rank[MAX_SLOTS];           // PE row for the current tick
+    int mem_blk[MAX_SLOTS];        // which 144-row block of mem_kv holds this slot's cross-attention K/V
+    int max_len[MAX_SLOTS];
+    int stop_on_eos[MAX_SLOTS];
 };
 
 struct DecLayerW {
@@ -42,19 +53,39 @@ struct DecWeights {
 
 struct DecBuffers {
     DecState* st;
-    float *x, *q, *ctx, *h;                    // [32,256] x3, [32,1024]
-    float *self_k, *self_v;                    // [layers, max_batch, heads, T, 32]
-    float *memory;                             // [max_batch*S, 256]
-    float *mem_kv;                             // [max_batch*S, layers*512]
-    float *edge_g, *edge_uv, *edge_prob;       // [B*kmax,256], [B*kmax,512], [B,kmax,kmax,8]
-    int T, S, max_batch, kmax;
+    float *x, *q, *ctx, *h;                    // [slots,256] x3, [slots,1024]
+    float *self_k, *self_v;                    // [layers, slots, heads, T, 32]
+    float *memory;                             // [32*S, 256]   scratch of one admission
+    float *mem_kv;                             // [mem_blocks, S, layers*512]
+    int* tokens;                               // [slots, T]
+    float* logp;                               // [slots, T]
+    float* hidden;                             // [slots, T, 256]
+    float *edge_g, *edge_uv, *edge_prob;       // [32*kmax,256], [32*kmax,512], [32,kmax,kmax,8]
+    int T, S, slots, mem_blocks, kmax;
 };
 
-hipError_t dec_enqueue_init(const DecBuffers& b, const int* chunk_dev, int B, hipStream_t s);
-hipError_t dec_enqueue_step(const DecWeights& w, const DecBuffers& b, int B, int max_len, int stop_on_eos,
-                            int* tokens, float* token_logp, float* hidden, float* logits_trace, hipStream_t s);
-hipError_t edges_enqueue(const DecWeights& w, const DecBuffers& bf, const float* hidden, const int* atom_idx,
-                         const int* n_atoms, int B, int kmax, int max_len, unsigned char* edges, double* scores,
-                         hipStream_t s);
+// token classes for the on-device atom-position scan (CharTokenizer.sequence_to_smiles 'indices')
+struct TokenClasses {
+    unsigned char flags[256];      // bit0 is_symbol, bit1 is_atom
+    int lbracket, rbracket, id_C, id_l, id_B, id_r, x0, y0, vocab;
+};
+
+hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const int* rowc_dev, int n, int chunk_tag,
+                             int mem_blk0, int max_len, int stop_on_eos, hipStream_t s);
+hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s);
+hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s);
+hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots, float* logits_trace,
+                            int trace_rows, hipStream_t s);
+hipError_t dec_enqueue_admit_rows(const DecBuffers& b, const int* chunk_ids_dev, int n, int max_len, int stop_on_eos,
+                                  hipStream_t s);
+hipError_t gather_enqueue(const DecBuffers& b, const int* slots_dev, int n_rows, int out_len, int* o_tokens, int* o_len,
+                          float* o_logp, float* o_hidden, hipStream_t s);
+hipError_t atoms_enqueue(const DecBuffers& b, const TokenClasses* tc_dev, const int* slots_dev, int n, int kmax,
+                         int* atom_idx, int* n_atoms, hipStream_t s);
+hipError_t atoms_enqueue_raw(const TokenClasses* tc_dev, const int* tokens, const int* lens, int n, int T, int kmax,
+                             int* atom_idx, int* n_atoms, hipStream_t s);
+hipError_t edges_enqueue(const DecWeights& w, const DecBuffers& bf, const float* hidden, const int* slot_map,
+                         const int* atom_idx, const int* n_atoms, int B, int kmax, int row_stride_T,
+                         unsigned char* edges, double* scores, hipStream_t s);
 
 }  // namespace mnx

@@ -67,86 +67,79 @@ hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, fl
 }
 
 // =============================================================================================
-// Skinny linear for the decode step: out[r, n] = epi( pro(in)[r, :] . W[n, :] + b[n] ), r < B <= 32.
-//   One workgroup = 8 output columns x all rows; the [B, 256] input slab is staged in LDS (and layer-normed
-//   there when PRO says so — every workgroup recomputes the tiny LN rather than paying a kernel boundary).
-//   Thread (r = tid & 31, c = tid >> 5).
-// PRO: 0 plain input | 1 LayerNorm(gamma, beta, eps 1e-6) | 2 token embedding + row-PE, then LayerNorm
-// EPI: 0 q/k/v scatter (q scaled, k/v appended to the self cache at position `step`)
-//      1 x[r, n] += result (residual, in place)   2 q-scale store   3 GELU store
+// Decode tick. Rows are SLOTS (dec_types.h): up to 256 sequences resident at once, each at its own position t.
+// One tick advances every alive slot by one token:
+//   dec_begin_kernel                  PE ranks of every slot, alive counters
+//   per layer (8 kernels)             dec_linear<LN1|embed, qkv>, dec_attn(self), dec_linear<wo,+res>,
+//                                     dec_linear<LN2, q>, dec_attn(cross), dec_linear<wo2,+res>,
+//                                     dec_linear<LN, w1, GELU>, dec_linear<w2,+res>
+//   dec_head_kernel                   final LN, logits, log-softmax, grammar mask, argmax, bookkeeping
+// All kernels read positions / alive flags from device memory, so one hipGraph per slot count replays forever.
 // =============================================================================================
+
+// Skinny linear: out[r, n] = epi( pro(in)[r, :] . W[n, :] + b[n] ) for the 32 slots of row tile blockIdx.y.
+//   One workgroup = 8 output columns x 32 rows; the [32, 256] input slab is staged in LDS (layer-normed in
+//   registers on the way when PRO says so — every workgroup recomputes the tiny LN rather than paying a kernel
+//   boundary). Thread (r = tid & 31, c = tid >> 5).
+// PRO: 0 plain input | 1 LayerNorm(gamma, beta, eps 1e-6) | 2 token embedding + row-PE, then LayerNorm
+// EPI: 0 q/k/v scatter (q scaled, k/v appended to the self cache at position t[slot])
+//      1 x[r, n] += result (residual, in place)   2 q-scale store   3 GELU store
 constexpr int TN = 8, XS = 260;
 
 struct LinArgs {
-    const float* in;      // [B, K]      (PRO 2: unused)
+    const float* in;      // [slots, K]      (PRO 2: unused)
     const float* W;       // [N, K]
     const float* bias;    // [N]
     const float* gamma;   // LN weight / bias (PRO 1, 2)
     const float* beta;
-    float* out;           // EPI 1: x [B, N] in place; EPI 2/3: [B, N]; EPI 0: q buffer [B, 256]
-    float* kcache;        // EPI 0: this layer's self K cache [B, heads, T, 32]
+    float* out;           // EPI 1: x [slots, N] in place; EPI 2/3: [slots, N]; EPI 0: q buffer [slots, 256]
+    float* kcache;        // EPI 0: this layer's self K cache [slots, heads, T, 32]
     float* vcache;
-    float* x_write;       // PRO 2: residual stream x [B, 256] written by workgroup 0
+    float* x_write;       // PRO 2: residual stream x [slots, 256] written by column-block 0
     const float* emb;     // PRO 2: [V, 256]
     const float* pe;      // PRO 2: [pe_len, 256]
-    DecState* st;
-    int B, N, K, T, heads;
+    const DecState* st;
+    int N, K, T, heads;
 };
 
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[32 * XS];
     __shared__ __attribute__((aligned(16))) float ws[TN * XS];
-    __shared__ int s_tok[32], s_rank[32];
     const int tid = threadIdx.x;
     const int r = tid & 31, c = tid >> 5;
     const int n0 = blockIdx.x * TN;
-    const int B = a.B;
+    const int slot0 = blockIdx.y * ROW_TILE;
     // LayerNorm / embedding thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
     const int lrow = tid >> 3, part = tid & 7;
-    if (PRO == 2) {
-        // PE row of every slot = rank among the still-alive rows of its reference batch chunk: the reference
-        // adds a sequence-first PE table to a batch-first tensor and compacts finished rows out of the batch
-        // (components.py:290, embedding.py:52-59, greedy_search.py:182-190).
-        if (tid < 32) {
-            const int alive = tid < B ? a.st->alive[tid] : 0;
-            const int chunk = tid < B ? a.st->chunk[tid] : -1;
-            int rank = 0;
-            for (int q = 0; q < 32; ++q) {
-                const int aq = __shfl(alive, q, 64), cq = __shfl(chunk, q, 64);
-                rank += (q < tid && aq != 0 && cq == chunk);
-            }
-            s_rank[tid] = rank;
-            s_tok[tid] = tid < B ? a.st->prev_tok[tid] : 0;
-        }
-        __syncthreads();
-    }
+    const bool live = a.st->alive[slot0 + lrow] != 0;
+    if (!__syncthreads_or(live)) return;            // whole tile idle
     float acc = 0.f;
     for (int k0 = 0; k0 < a.K; k0 += 256) {
-        // ---- stage the input slab [B, 256] and the weight tile [8, 256]: all loads first, then LDS stores ----
+        // ---- stage the input slab [32, 256] and the weight tile [8, 256]: all loads first, then LDS stores ----
         f32x4 xv[8], wv[2];
         if (PRO == 2) {
-            // x0[r] = E[tok_r] * sqrt(256) + pe[rank_r]
-            const float* e = a.emb + (size_t)s_tok[lrow] * 256 + part * 4;
-            const float* p = a.pe + (size_t)s_rank[lrow] * 256 + part * 4;
+            // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
+            const float* e = a.emb + (size_t)a.st->prev_tok[slot0 + lrow] * 256 + part * 4;
+            const float* p = a.pe + (size_t)a.st->rank[slot0 + lrow] * 256 + part * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                xv[j] = lrow < B ? *(const f32x4*)(e + 32 * j) * 16.0f + *(const f32x4*)(p + 32 * j)
-                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+                xv[j] = live ? *(const f32x4*)(e + 32 * j) * 16.0f + *(const f32x4*)(p + 32 * j)
+                             : (f32x4){0.f, 0.f, 0.f, 0.f};
         } else {
-            const float* src = a.in + (size_t)lrow * a.K + k0 + part * 4;
+            const float* src = a.in + (size_t)(slot0 + lrow) * a.K + k0 + part * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                xv[j] = lrow < B ? *(const f32x4*)(src + 32 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                xv[j] = live ? *(const f32x4*)(src + 32 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = tid + 256 * j, nn = i >> 6, q = i & 63;
             wv[j] = *(const f32x4*)(a.W + (size_t)(n0 + nn) * a.K + k0 + q * 4);
         }
-        if (PRO == 2 && blockIdx.x == 0 && lrow < B) {
+        if (PRO == 2 && blockIdx.x == 0 && live) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *(f32x4*)(a.x_write + lrow * 256 + part * 4 + 32 * j) = xv[j];
+            for (int j = 0; j < 8; ++j) *(f32x4*)(a.x_write + (size_t)(slot0 + lrow) * 256 + part * 4 + 32 * j) = xv[j];
         }
         if (PRO != 0) {  // LayerNorm in registers: 8 lanes per row, two-pass (K == 256)
             float s = 0.f;
@@ -189,52 +182,54 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
         acc += (a0 + a1) + (a2 + a3);
         __syncthreads();
     }
-    if (r >= B) return;
+    const int slot = slot0 + r;
+    if (!a.st->alive[slot]) return;
     const int n = n0 + c;
     float v = acc + a.bias[n];
     if (EPI == 0) {
-        const int part = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
-        if (part == 0) {
-            a.out[r * 256 + ch] = v * 0.17677669529663687f;  // q / sqrt(32) before QK^T (onmt MultiHeadedAttention)
+        const int part_ = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
+        if (part_ == 0) {
+            a.out[(size_t)slot * 256 + ch] = v * 0.17677669529663687f;  // q / sqrt(32) before QK^T (onmt MHA)
         } else {
-            const int step = a.st->step;
-            float* cache = part == 1 ? a.kcache : a.vcache;
-            cache[(((size_t)r * a.heads + hd) * a.T + step) * 32 + d] = v;
+            float* cache = part_ == 1 ? a.kcache : a.vcache;
+            cache[(((size_t)slot * a.heads + hd) * a.T + a.st->t[slot]) * 32 + d] = v;
         }
     } else if (EPI == 1) {
-        a.out[(size_t)r * a.N + n] += v;
+        a.out[(size_t)slot * a.N + n] += v;
     } else if (EPI == 2) {
-        a.out[(size_t)r * a.N + n] = v * 0.17677669529663687f;
+        a.out[(size_t)slot * a.N + n] = v * 0.17677669529663687f;
     } else {
-        a.out[(size_t)r * a.N + n] = gelu_erf(v);
+        a.out[(size_t)slot * a.N + n] = gelu_erf(v);
     }
 }
 
 // =============================================================================================
-// Single-query attention, one wave per (row, head): softmax(q.K^T) . V over `nkeys` keys (fp32 throughout,
-// as onmt: scores.float(), no mask for a single query position). Keys of one (row, head) are `kstride`
-// floats apart (32 in the self cache, 2*d_model in the projected memory).
+// Single-query attention, one wave per (slot, head): softmax(q.K^T) . V (fp32 throughout, as onmt:
+// scores.float(), no mask for a single query position). Self: keys 0..t[slot] of the slot's cache (32 floats
+// apart). Cross: the 144 projected memory rows of the slot's memory block (`kstride` floats apart).
 // =============================================================================================
 struct AttnArgs {
-    const float* q;      // [B, 256] pre-scaled
+    const float* q;      // [slots, 256] pre-scaled
     const float* K;      // base of this layer's keys
     const float* V;
-    float* ctx;          // [B, 256]
+    float* ctx;          // [slots, 256]
     const DecState* st;
     long long row_stride, head_stride;   // floats
-    int kstride, fixed_keys, heads;
+    int kstride, fixed_keys, heads, cross;
 };
 
 __global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
     __shared__ float ps[512];
     const int lane = threadIdx.x;
-    const int r = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
-    const int nkeys = a.fixed_keys > 0 ? a.fixed_keys : a.st->step + 1;
-    const float* Kb = a.K + r * a.row_stride + hd * a.head_stride;
-    const float* Vb = a.V + r * a.row_stride + hd * a.head_stride;
+    const int slot = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
+    if (!a.st->alive[slot]) return;
+    const int nkeys = a.cross ? a.fixed_keys : a.st->t[slot] + 1;
+    const long long rowb = a.cross ? (long long)a.st->mem_blk[slot] : (long long)slot;
+    const float* Kb = a.K + rowb * a.row_stride + hd * a.head_stride;
+    const float* Vb = a.V + rowb * a.row_stride + hd * a.head_stride;
     f32x4 q[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + r * 256 + hd * 32 + i * 4);
+    for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + (size_t)slot * 256 + hd * 32 + i * 4);
     float sc[8];
     float mx = -3.0e38f;
 #pragma unroll
@@ -284,27 +279,27 @@ __global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
         o[i] += __shfl_xor(o[i], 16, 64);
         o[i] += __shfl_xor(o[i], 32, 64);
     }
-    if (lane < 8) *(f32x4*)(a.ctx + r * 256 + hd * 32 + dq * 4) = o * (1.0f / sum);
+    if (lane < 8) *(f32x4*)(a.ctx + (size_t)slot * 256 + hd * 32 + dq * 4) = o * (1.0f / sum);
 }
 
 // =============================================================================================
-// Head of the step: final LayerNorm -> hidden state (kept for the bond head) -> output_layer -> log_softmax
-// -> grammar mask -> EOS ban at step 0 -> argmax -> per-row bookkeeping.
+// Head of the tick: final LayerNorm -> hidden state (kept for the bond head) -> output_layer -> log_softmax
+// -> grammar mask -> EOS ban at position 0 -> argmax -> per-slot bookkeeping.
 //   reference models/decoder.py:470, components.py:296-306, tokenization.py:383-392,
 //   decode_strategy.py:50-56, greedy_search.py:139-161
 // =============================================================================================
 struct HeadArgs {
-    const float* x;        // [B, 256]
+    const float* x;        // [slots, 256]
     const float* gamma;
     const float* beta;
     const float* wout_t;   // [256, VP]  (output_layer.weight transposed, padded)
     const float* bout;     // [V]
     DecState* st;
-    int* tokens;           // [B, max_len]
-    float* token_logp;     // [B, max_len]
-    float* hidden;         // [B, max_len, 256]
-    float* logits_trace;   // [max_len, B, V] or null
-    int B, V, VP, max_len, x0, y0, eos, stop_on_eos;
+    int* tokens;           // [slots, T]
+    float* token_logp;     // [slots, T]
+    float* hidden;         // [slots, T, 256]
+    float* logits_trace;   // [T, trace_rows, V] or null (slots 0..trace_rows-1)
+    int V, VP, T, x0, y0, eos, trace_rows;
 };
 
 __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
@@ -312,23 +307,23 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __shared__ float red[8];
     __shared__ int redi[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = blockIdx.x;
-    const int t = a.st->step;
+    const int slot = blockIdx.x;
+    if (!a.st->alive[slot]) return;
+    const int t = a.st->t[slot];
     if (wave == 0) {
-        f32x4 v = *(const f32x4*)(a.x + r * 256 + lane * 4);
+        f32x4 v = *(const f32x4*)(a.x + (size_t)slot * 256 + lane * 4);
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
         v -= mean;
         const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
         const f32x4 o = v * rsqrtf(var + 1e-6f) * *(const f32x4*)(a.gamma + lane * 4) + *(const f32x4*)(a.beta + lane * 4);
         *(f32x4*)(hv + lane * 4) = o;
-        if (t < a.max_len) *(f32x4*)(a.hidden + ((size_t)r * a.max_len + t) * 256 + lane * 4) = o;
+        *(f32x4*)(a.hidden + ((size_t)slot * a.T + t) * 256 + lane * 4) = o;
     }
     __syncthreads();
     const bool valid = tid < a.V;
     float logit = -3.0e38f;
     if (valid) {
-        float s = 0.f;
-        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
         for (int k = 0; k < 256; k += 4) {     // 32 independent coalesced loads in flight per unrolled body
             s = fmaf(hv[k], a.wout_t[k * a.VP + tid], s);
@@ -337,7 +332,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
             s3 = fmaf(hv[k + 3], a.wout_t[(k + 3) * a.VP + tid], s3);
         }
         logit = (s + s1) + (s2 + s3) + a.bout[tid];
-        if (a.logits_trace && t < a.max_len) a.logits_trace[((size_t)t * a.B + r) * a.V + tid] = logit;
+        if (a.logits_trace && slot < a.trace_rows) a.logits_trace[((size_t)t * a.trace_rows + slot) * a.V + tid] = logit;
     }
     // log_softmax
     float m = wave_max(logit);
@@ -350,7 +345,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __syncthreads();
     const float lse = m + logf(red[4] + red[5] + red[6] + red[7]);
     float lp = logit - lse;
-    const int prev = a.st->prev_tok[r];
+    const int prev = a.st->prev_tok[slot];
     if (prev >= a.x0 && prev < a.y0) { if (tid < a.y0) lp = -10000.0f; }     // after an x-bin: only y-bins
     else if (prev >= a.y0)           { if (tid >= a.x0) lp = -10000.0f; }    // after a y-bin: no coordinate bins
     if (t == 0 && tid == a.eos) lp = -1e20f;                                  // min_length = 1
@@ -370,93 +365,181 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
-        if (a.st->alive[r] && t < a.max_len) {
-            a.tokens[(size_t)r * a.max_len + t] = bi;
-            a.token_logp[(size_t)r * a.max_len + t] = bv;
-            a.st->prev_tok[r] = bi;
-            a.st->len[r] = t + 1;
-            if ((a.stop_on_eos && bi == a.eos) || t + 1 >= a.max_len) a.st->alive[r] = 0;
-        }
+        a.tokens[(size_t)slot * a.T + t] = bi;
+        a.token_logp[(size_t)slot * a.T + t] = bv;
+        a.st->prev_tok[slot] = bi;
+        a.st->len[slot] = t + 1;
+        a.st->t[slot] = t + 1;
+        if ((a.st->stop_on_eos[slot] && bi == a.eos) || t + 1 >= a.st->max_len[slot]) a.st->alive[slot] = 0;
     }
 }
 
-// Closes a step: publishes the next step index and the number of rows still decoding (polled by the host).
-// A separate 1-thread kernel: the kernel boundary is the cheapest correct all-rows barrier on this chip.
-__global__ void dec_advance_kernel(DecState* st, int B) {
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int q = 0; q < B; ++q) n += st->alive[q] != 0;
-        st->n_alive = n;
-        st->step = st->step + 1;
+// Opens a tick: PE rank of every slot (rank among the alive slots of its chunk, by row index) and the alive
+// counters the host polls. One workgroup; the kernel boundary is the all-rows barrier.
+__global__ __launch_bounds__(256) void dec_begin_kernel(DecState* st, int slots) {
+    __shared__ int s_alive[MAX_SLOTS], s_chunk[MAX_SLOTS], s_rowc[MAX_SLOTS], s_cnt[MAX_CHUNKS];
+    const int tid = threadIdx.x;
+    if (tid < MAX_CHUNKS) s_cnt[tid] = 0;
+    const int al = tid < slots ? st->alive[tid] : 0;
+    s_alive[tid] = al;
+    s_chunk[tid] = tid < slots ? st->chunk[tid] : -1;
+    s_rowc[tid] = tid < slots ? st->rowc[tid] : 0;
+    __syncthreads();
+    if (al) {
+        const int c = s_chunk[tid], rc = s_rowc[tid];
+        int rank = 0;
+        for (int q = 0; q < slots; ++q) rank += (s_alive[q] != 0 && s_chunk[q] == c && s_rowc[q] < rc);
+        st->rank[tid] = rank;
+        atomicAdd(&s_cnt[c & (MAX_CHUNKS - 1)], 1);
     }
+    const int n = __syncthreads_count(al != 0);
+    if (tid < MAX_CHUNKS) st->chunk_alive[tid] = s_cnt[tid];
+    if (tid == 0) { st->n_active = n; st->tick = st->tick + 1; }
 }
 
-__global__ void dec_init_kernel(DecState* st, const int* chunk, int B, int sos) {
+__global__ void dec_reset_kernel(DecState* st) {
     const int i = threadIdx.x;
-    if (i == 0) { st->step = 0; st->ticket = 0; st->n_alive = B; }
-    if (i < 32) {
-        st->alive[i] = i < B;
-        st->prev_tok[i] = sos;
-        st->len[i] = 0;
-        st->chunk[i] = (chunk && i < B) ? chunk[i] : 0;
+    if (i == 0) { st->tick = 0; st->n_active = 0; }
+    if (i < MAX_CHUNKS) st->chunk_alive[i] = 0;
+    if (i < MAX_SLOTS) { st->alive[i] = 0; st->t[i] = 0; st->len[i] = 0; st->chunk[i] = -1; st->rank[i] = 0; }
+}
+
+// Admit n rows of one reference batch into the given slots (any free slots).
+__global__ void dec_admit_kernel(DecState* st, const int* slots, const int* rowc, int n, int chunk_tag, int mem_blk0,
+                                 int max_len, int stop_on_eos, int sos) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        const int s = slots[i];
+        st->alive[s] = 1; st->t[s] = 0; st->prev_tok[s] = sos; st->len[s] = 0;
+        st->chunk[s] = chunk_tag; st->rowc[s] = rowc ? rowc[i] : i; st->rank[s] = 0;
+        st->mem_blk[s] = mem_blk0 + i; st->max_len[s] = max_len; st->stop_on_eos[s] = stop_on_eos;
     }
+    if (i == 0) { atomicAdd(&st->n_active, n); atomicAdd(&st->chunk_alive[chunk_tag], n); }
 }
 
-// ---- host-side enqueue of one decode step (captured into a hipGraph by engine.cpp) ------------
+// ---- host-side enqueue helpers (engine.hip captures the tick into a hipGraph) -----------------
 template <int PRO, int EPI>
-static void lin(hipStream_t s, const LinArgs& a) {
-    hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN), dim3(256), 0, s, a);
+static void lin(hipStream_t s, const LinArgs& a, int slots) {
+    hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
 }
 
-hipError_t dec_enqueue_init(const DecBuffers& b, const int* chunk_dev, int B, hipStream_t s) {
-    hipLaunchKernelGGL(dec_init_kernel, dim3(1), dim3(64), 0, s, b.st, chunk_dev, B, 1);
+hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s) {
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(256), 0, s, b.st, slots);
     return hipGetLastError();
 }
 
-hipError_t dec_enqueue_step(const DecWeights& w, const DecBuffers& b, int B, int max_len, int stop_on_eos,
-                            int* tokens, float* token_logp, float* hidden, float* logits_trace, hipStream_t s) {
+hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s) {
+    hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(256), 0, s, b.st);
+    return hipGetLastError();
+}
+
+hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const int* rowc_dev, int n, int chunk_tag,
+                             int mem_blk0, int max_len, int stop_on_eos, hipStream_t s) {
+    hipLaunchKernelGGL(dec_admit_kernel, dim3(1), dim3(64), 0, s, b.st, slots_dev, rowc_dev, n, chunk_tag, mem_blk0,
+                       max_len, stop_on_eos, 1);
+    return hipGetLastError();
+}
+
+hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots, float* logits_trace,
+                            int trace_rows, hipStream_t s) {
     const int D = 256, H = w.heads, T = b.T;
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(256), 0, s, b.st, slots);
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& L = w.L[l];
-        float* kc = b.self_k + (size_t)l * b.max_batch * H * T * 32;
-        float* vc = b.self_v + (size_t)l * b.max_batch * H * T * 32;
+        float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;
+        float* vc = b.self_v + (size_t)l * b.slots * H * T * 32;
         LinArgs a = {};
-        a.st = b.st; a.B = B; a.T = T; a.heads = H;
+        a.st = b.st; a.T = T; a.heads = H;
         // LN1 (+ embedding at layer 0) -> q, k, v
         a.in = b.x; a.W = L.wqkv; a.bias = L.bqkv; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.out = b.q;
         a.kcache = kc; a.vcache = vc; a.x_write = b.x; a.emb = w.emb; a.pe = w.pe; a.N = 3 * D; a.K = D;
-        if (l == 0) lin<2, 0>(s, a); else lin<1, 0>(s, a);
+        if (l == 0) lin<2, 0>(s, a, slots); else lin<1, 0>(s, a, slots);
         AttnArgs at = {};
-        at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H;
+        at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
         at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32; at.fixed_keys = 0;
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(B * H), dim3(64), 0, s, at);
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(64), 0, s, at);
         // self final_linear + residual
         a.in = b.ctx; a.W = L.wo; a.bias = L.bo; a.out = b.x; a.N = D; a.K = D;
-        lin<0, 1>(s, a);
+        lin<0, 1>(s, a, slots);
         // LN2 -> context query
         a.in = b.x; a.W = L.wq2; a.bias = L.bq2; a.gamma = L.ln2_g; a.beta = L.ln2_b; a.out = b.q;
-        lin<1, 2>(s, a);
-        at.K = b.mem_kv + (size_t)l * 2 * D;          // memory K/V: [B*S, layers*2*D], layer l keys then values
+        lin<1, 2>(s, a, slots);
+        at.K = b.mem_kv + (size_t)l * 2 * D;          // memory K/V: [block*S + s][layers*2*D], layer l keys then values
         at.V = at.K + D;
         at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = 32; at.kstride = w.layers * 2 * D;
-        at.fixed_keys = b.S;
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(B * H), dim3(64), 0, s, at);
+        at.fixed_keys = b.S; at.cross = 1;
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(64), 0, s, at);
         // context final_linear + residual
         a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = b.x;
-        lin<0, 1>(s, a);
+        lin<0, 1>(s, a, slots);
         // feed-forward: LN -> w_1 -> GELU -> w_2 -> + residual
         a.in = b.x; a.W = L.w1; a.bias = L.b1; a.gamma = L.lnf_g; a.beta = L.lnf_b; a.out = b.h; a.N = w.dff;
-        lin<1, 3>(s, a);
+        lin<1, 3>(s, a, slots);
         a.in = b.h; a.W = L.w2; a.bias = L.b2; a.out = b.x; a.N = D; a.K = w.dff;
-        lin<0, 1>(s, a);
+        lin<0, 1>(s, a, slots);
     }
     HeadArgs h = {};
     h.x = b.x; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
-    h.tokens = tokens; h.token_logp = token_logp; h.hidden = hidden; h.logits_trace = logits_trace;
-    h.B = B; h.V = w.vocab; h.VP = w.vpad; h.max_len = max_len; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
-    h.eos = 2; h.stop_on_eos = stop_on_eos;
-    hipLaunchKernelGGL(dec_head_kernel, dim3(B), dim3(256), 0, s, h);
-    hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, s, b.st, B);
+    h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
+    h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
+    h.eos = 2; h.trace_rows = trace_rows;
+    hipLaunchKernelGGL(dec_head_kernel, dim3(slots), dim3(256), 0, s, h);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// On-device atom positions: the 'indices' that CharTokenizer.sequence_to_smiles derives from a decoded id
+// sequence (reference tokenization.py:464-515): for every atom token group followed by "x y <next>", the
+// position of <next>. One thread per sequence (a <= 480-step scan).
+// =============================================================================================
+__global__ void atom_scan_kernel(const int* __restrict__ lens, const int* __restrict__ tokens,
+                                 const TokenClasses* __restrict__ tc, const int* __restrict__ slots, int n_rows, int T,
+                                 int kmax, int* __restrict__ atom_idx, int* __restrict__ n_atoms) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const int slot = slots ? slots[row] : row;
+    const int* seq = tokens + (size_t)slot * T;
+    const int n = lens[slot];
+    int i = 0, k = 0;
+    while (i < n) {
+        const int t = seq[i];
+        if (t == 2 || t == 0) break;                                  // <eos> / <pad>
+        if (t >= tc->x0) { ++i; continue; }                           // coordinate bins
+        if (!(tc->flags[t] & 2)) { ++i; continue; }                   // not an atom token
+        int j;
+        if (t == tc->lbracket) {
+            j = i + 1;
+            while (j < n && seq[j] < tc->x0 && (tc->flags[seq[j]] & 1)) {
+                ++j;
+                if (seq[j - 1] == tc->rbracket) break;
+            }
+        } else if (i + 1 < n && ((t == tc->id_C && seq[i + 1] == tc->id_l) || (t == tc->id_B && seq[i + 1] == tc->id_r))) {
+            j = i + 2;
+        } else {
+            j = i + 1;
+        }
+        if (j + 2 < n && seq[j] >= tc->x0 && seq[j] < tc->y0 && seq[j + 1] >= tc->y0) {
+            if (k < kmax) atom_idx[(size_t)row * kmax + k] = j + 2;
+            ++k;
+            i = j + 2;
+        } else {
+            i = j;
+        }
+    }
+    n_atoms[row] = k < kmax ? k : kmax;
+}
+
+hipError_t atoms_enqueue(const DecBuffers& b, const TokenClasses* tc_dev, const int* slots_dev, int n, int kmax,
+                         int* atom_idx, int* n_atoms, hipStream_t s) {
+    hipLaunchKernelGGL(atom_scan_kernel, dim3((n + 63) / 64), dim3(64), 0, s, b.st->len, b.tokens, tc_dev, slots_dev, n,
+                       b.T, kmax, atom_idx, n_atoms);
+    return hipGetLastError();
+}
+
+hipError_t atoms_enqueue_raw(const TokenClasses* tc_dev, const int* tokens, const int* lens, int n, int T, int kmax,
+                             int* atom_idx, int* n_atoms, hipStream_t s) {
+    hipLaunchKernelGGL(atom_scan_kernel, dim3((n + 63) / 64), dim3(64), 0, s, lens, tokens, tc_dev, (const int*)nullptr,
+                       n, T, kmax, atom_idx, n_atoms);
     return hipGetLastError();
 }
 
@@ -465,13 +548,15 @@ hipError_t dec_enqueue_step(const DecWeights& w, const DecBuffers& b, int B, int
 //   logits[i,j] = W2 . GELU(W1a.h_i + W1b.h_j + b1) + b2 ; the two halves of the first Linear are applied
 //   once per atom (SGEMM above) instead of once per pair.
 // =============================================================================================
-__global__ void edge_gather_kernel(const float* __restrict__ hidden, const int* __restrict__ atom_idx,
-                                   const int* __restrict__ n_atoms, float* __restrict__ g, int kmax, int max_len) {
+__global__ void edge_gather_kernel(const float* __restrict__ hidden, const int* __restrict__ slot_map,
+                                   const int* __restrict__ atom_idx, const int* __restrict__ n_atoms,
+                                   float* __restrict__ g, int kmax, int max_len) {
     const int b = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
     int idx = i < n_atoms[b] ? atom_idx[b * kmax + i] : 0;
     idx = min(max(idx, 0), max_len - 1);
+    const size_t row = slot_map ? (size_t)slot_map[b] : (size_t)b;
     *(f32x4*)(g + ((size_t)b * kmax + i) * 256 + lane * 4) =
-        *(const f32x4*)(hidden + ((size_t)b * max_len + idx) * 256 + lane * 4);
+        *(const f32x4*)(hidden + (row * max_len + idx) * 256 + lane * 4);
 }
 
 // UV [B*kmax, 512]: cols 0..255 = W1a.h (+0), cols 256..511 = W1b.h + b1.  One workgroup per (b, i); lane = j.
@@ -545,17 +630,65 @@ __global__ void edge_sym_kernel(const float* __restrict__ prob, const int* __res
     if (scores) scores[((size_t)b * kmax + i) * kmax + j] = bv;
 }
 
-hipError_t edges_enqueue(const DecWeights& w, const DecBuffers& bf, const float* hidden, const int* atom_idx,
-                         const int* n_atoms, int B, int kmax, int max_len, unsigned char* edges, double* scores,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(edge_gather_kernel, dim3(kmax, B), dim3(64), 0, s, hidden, atom_idx, n_atoms, bf.edge_g, kmax,
-                       max_len);
+hipError_t edges_enqueue(const DecWeights& w, const DecBuffers& bf, const float* hidden, const int* slot_map,
+                         const int* atom_idx, const int* n_atoms, int B, int kmax, int max_len,
+                         unsigned char* edges, double* scores, hipStream_t s) {
+    hipLaunchKernelGGL(edge_gather_kernel, dim3(kmax, B), dim3(64), 0, s, hidden, slot_map, atom_idx, n_atoms,
+                       bf.edge_g, kmax, max_len);
     hipError_t e = launch_sgemm_tn(bf.edge_g, w.edge_w1cat, w.edge_b1cat, bf.edge_uv, B * kmax, 512, 256, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(edge_pair_kernel, dim3(kmax, B), dim3(256), 0, s, bf.edge_uv, w.edge_w2, w.edge_b2, n_atoms,
                        bf.edge_prob, kmax);
     hipLaunchKernelGGL(edge_sym_kernel, dim3((kmax + 63) / 64, kmax, B), dim3(64), 0, s, bf.edge_prob, n_atoms, edges,
                        scores, kmax);
+    return hipGetLastError();
+}
+
+}  // namespace mnx
+
+namespace mnx {
+
+// Gather per-slot results into the caller's per-image layout: out[row] <- slot buffers of slots[row].
+__global__ void rows_gather_kernel(const DecState* st, const int* __restrict__ slots, const int* __restrict__ tokens,
+                                   const float* __restrict__ logp, const float* __restrict__ hidden, int T, int out_len,
+                                   int* __restrict__ o_tokens, int* __restrict__ o_len, float* __restrict__ o_logp,
+                                   float* __restrict__ o_hidden) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int slot = slots ? slots[row] : row;
+    const int n = min(st->len[slot], out_len);
+    if (tid == 0) o_len[row] = n;
+    for (int i = tid; i < out_len; i += blockDim.x) {
+        o_tokens[(size_t)row * out_len + i] = i < n ? tokens[(size_t)slot * T + i] : 0;
+        if (o_logp) o_logp[(size_t)row * out_len + i] = i < n ? logp[(size_t)slot * T + i] : 0.f;
+    }
+    if (o_hidden) {
+        const f32x4* src = (const f32x4*)(hidden + (size_t)slot * T * 256);
+        f32x4* dst = (f32x4*)(o_hidden + (size_t)row * out_len * 256);
+        for (int i = tid; i < n * 64; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+hipError_t gather_enqueue(const DecBuffers& b, const int* slots_dev, int n_rows, int out_len, int* o_tokens, int* o_len,
+                          float* o_logp, float* o_hidden, hipStream_t s) {
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(n_rows), dim3(256), 0, s, b.st, slots_dev, b.tokens, b.logp, b.hidden,
+                       b.T, out_len, o_tokens, o_len, o_logp, o_hidden);
+    return hipGetLastError();
+}
+
+// admit variant used by mnx_decode_greedy: slot i = row i, chunk ids given per row on the device
+__global__ void dec_admit_rows_kernel(DecState* st, const int* chunk_ids, int n, int max_len, int stop_on_eos, int sos) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        st->alive[i] = 1; st->t[i] = 0; st->prev_tok[i] = sos; st->len[i] = 0;
+        st->chunk[i] = chunk_ids ? chunk_ids[i] : 0; st->rowc[i] = i; st->rank[i] = 0;
+        st->mem_blk[i] = i; st->max_len[i] = max_len; st->stop_on_eos[i] = stop_on_eos;
+    }
+    if (i == 0) st->n_active = n;
+}
+
+hipError_t dec_enqueue_admit_rows(const DecBuffers& b, const int* chunk_ids_dev, int n, int max_len, int stop_on_eos,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(dec_admit_rows_kernel, dim3(1), dim3(64), 0, s, b.st, chunk_ids_dev, n, max_len, stop_on_eos, 1);
     return hipGetLastError();
 }
 

@@ -33,10 +33,8 @@ struct StageW {
     int C = 0, heads = 0;
 };
 struct GraphKey {
-    int B, max_len, stop, trace;
-    bool operator<(const GraphKey& o) const {
-        return std::tie(B, max_len, stop, trace) < std::tie(o.B, o.max_len, o.stop, o.trace);
-    }
+    int slots, trace;
+    bool operator<(const GraphKey& o) const { return std::tie(slots, trace) < std::tie(o.slots, o.trace); }
 };
 
 }  // namespace
@@ -57,10 +55,17 @@ struct mnx_engine {
     // decoder
     DecWeights dw{};
     DecBuffers db{};
-    int *out_tokens = nullptr, *out_len_dummy = nullptr;
-    float *out_logp = nullptr, *out_hidden = nullptr, *out_trace = nullptr;
-    int* host_flag = nullptr;  // pinned
+    float* out_trace = nullptr;
+    int* host_flag = nullptr;  // pinned: [2][1 + MAX_CHUNKS] poll snapshots + slot lists
     std::map<GraphKey, hipGraphExec_t> graphs;
+    // continuous-batching pipeline (mnx_predict)
+    hipStream_t enc_stream = nullptr;
+    float* feat_ring[2] = {nullptr, nullptr};
+    hipEvent_t ev_enc_done[2] = {nullptr, nullptr}, ev_feat_free[2] = {nullptr, nullptr}, ev_poll[2] = {nullptr, nullptr};
+    int* slot_lists = nullptr;          // device [MAX_CHUNKS][32]
+    TokenClasses* tc_dev = nullptr;
+    bool have_tc = false;
+    int n_chunk_bufs = 0;
     bool use_graph = true;
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
     // profiling (bench aid)
@@ -178,7 +183,7 @@ int check_cfg(const mnx_config& c, std::string& why) {
     if (c.max_batch < 1) return bad("max_batch < 1");
     if (c.max_atoms < 1 || c.max_atoms > 256) return bad("max_atoms must be 1..256");
     if (c.compute_dtype != MNX_DTYPE_BF16 && c.compute_dtype != MNX_DTYPE_FP16) return bad("compute_dtype");
-    if (c.pe_len < MAX_ROWS) return bad("pe_len too small");
+    if (c.pe_len < ROW_TILE) return bad("pe_len too small");
     return MNX_OK;
 }
 
@@ -197,6 +202,12 @@ void mnx_destroy(mnx_engine* h) {
     hipSetDevice(h->device);
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
+    if (h->enc_stream) hipStreamDestroy(h->enc_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (h->ev_enc_done[i]) hipEventDestroy(h->ev_enc_done[i]);
+        if (h->ev_feat_free[i]) hipEventDestroy(h->ev_feat_free[i]);
+        if (h->ev_poll[i]) hipEventDestroy(h->ev_poll[i]);
+    }
     for (auto& ev : h->ev_pool) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (void* p : h->allocs) hipFree(p);
     if (h->host_flag) hipHostFree(h->host_flag);
@@ -428,25 +439,37 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->attn16 = P.dalloc(MB * max_xn * 2);
     h->h16 = P.dalloc(MB * max_h * 2);
     DecBuffers& db = h->db;
-    db.T = c.max_len; db.S = (int)S; db.max_batch = MAX_ROWS; db.kmax = c.max_atoms;
+    const int SL = MAX_SLOTS;
+    h->n_chunk_bufs = 24;
+    db.T = c.max_len; db.S = (int)S; db.slots = SL; db.mem_blocks = h->n_chunk_bufs * ROW_TILE; db.kmax = c.max_atoms;
     db.st = (DecState*)P.dalloc(sizeof(DecState));
-    db.x = (float*)P.dalloc(MAX_ROWS * D * 4);
-    db.q = (float*)P.dalloc(MAX_ROWS * D * 4);
-    db.ctx = (float*)P.dalloc(MAX_ROWS * D * 4);
-    db.h = (float*)P.dalloc(MAX_ROWS * FF * 4);
-    const size_t cache = (size_t)c.dec_layers * MAX_ROWS * c.dec_heads * c.max_len * 32;
+    db.x = (float*)P.dalloc((size_t)SL * D * 4);
+    db.q = (float*)P.dalloc((size_t)SL * D * 4);
+    db.ctx = (float*)P.dalloc((size_t)SL * D * 4);
+    db.h = (float*)P.dalloc((size_t)SL * FF * 4);
+    const size_t cache = (size_t)c.dec_layers * SL * c.dec_heads * c.max_len * 32;
     db.self_k = (float*)P.dalloc(cache * 4);
     db.self_v = (float*)P.dalloc(cache * 4);
-    db.memory = (float*)P.dalloc((size_t)MAX_ROWS * S * D * 4);
-    db.mem_kv = (float*)P.dalloc((size_t)MAX_ROWS * S * c.dec_layers * 2 * D * 4);
-    db.edge_g = (float*)P.dalloc((size_t)MAX_ROWS * db.kmax * D * 4);
-    db.edge_uv = (float*)P.dalloc((size_t)MAX_ROWS * db.kmax * 2 * D * 4);
-    db.edge_prob = (float*)P.dalloc((size_t)MAX_ROWS * db.kmax * db.kmax * 8 * 4);
-    h->out_tokens = (int*)P.dalloc((size_t)MAX_ROWS * c.max_len * 4);
-    h->out_logp = (float*)P.dalloc((size_t)MAX_ROWS * c.max_len * 4);
-    h->out_hidden = (float*)P.dalloc((size_t)MAX_ROWS * c.max_len * D * 4);
+    db.memory = (float*)P.dalloc((size_t)ROW_TILE * S * D * 4);
+    db.mem_kv = (float*)P.dalloc((size_t)db.mem_blocks * S * c.dec_layers * 2 * D * 4);
+    db.tokens = (int*)P.dalloc((size_t)SL * c.max_len * 4);
+    db.logp = (float*)P.dalloc((size_t)SL * c.max_len * 4);
+    db.hidden = (float*)P.dalloc((size_t)SL * c.max_len * D * 4);
+    db.edge_g = (float*)P.dalloc((size_t)ROW_TILE * db.kmax * D * 4);
+    db.edge_uv = (float*)P.dalloc((size_t)ROW_TILE * db.kmax * 2 * D * 4);
+    db.edge_prob = (float*)P.dalloc((size_t)ROW_TILE * db.kmax * db.kmax * 8 * 4);
     h->out_trace = nullptr;   // allocated lazily on first traced decode (test aid)
-    if (hipHostMalloc((void**)&h->host_flag, 64) != hipSuccess) P.problems.push_back("hipHostMalloc failed");
+    h->feat_ring[0] = (float*)P.dalloc((size_t)ROW_TILE * S * CF * 4);
+    h->feat_ring[1] = (float*)P.dalloc((size_t)ROW_TILE * S * CF * 4);
+    h->slot_lists = (int*)P.dalloc((size_t)MAX_CHUNKS * ROW_TILE * 4);
+    h->tc_dev = (TokenClasses*)P.dalloc(sizeof(TokenClasses));
+    if (hipStreamCreateWithFlags(&h->enc_stream, hipStreamNonBlocking) != hipSuccess) P.problems.push_back("stream create failed");
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&h->ev_enc_done[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_feat_free[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_poll[i], hipEventDisableTiming) != hipSuccess)
+            P.problems.push_back("event create failed");
+    if (hipHostMalloc((void**)&h->host_flag, 4096) != hipSuccess) P.problems.push_back("hipHostMalloc failed");
 
     if (!P.problems.empty()) {
         g_create_error = "mnx_create: " + std::to_string(P.problems.size()) + " problem(s):";
@@ -537,12 +560,42 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     return MNX_OK;
 }
 
+static int get_tick_graph(mnx_engine* h, int slots, float* trace, int trace_rows, hipStream_t s, hipGraphExec_t* out) {
+    *out = nullptr;
+    if (!h->use_graph) return MNX_OK;
+    GraphKey key{slots, trace ? trace_rows : 0};
+    auto it = h->graphs.find(key);
+    if (it != h->graphs.end()) { *out = it->second; return MNX_OK; }
+    hipGraph_t g = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, trace, trace_rows, s);
+    hipError_t e2 = hipStreamEndCapture(s, &g);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        h->err = std::string("decode tick capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+        return MNX_ERR_HIP;
+    }
+    HIPCHK(h, hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    h->graphs[key] = exec;
+    *out = exec;
+    return MNX_OK;
+}
+
+static int run_ticks(mnx_engine* h, hipGraphExec_t exec, int slots, float* trace, int trace_rows, int n, hipStream_t s) {
+    for (int i = 0; i < n; ++i) {
+        if (exec) HIPCHK(h, hipGraphLaunch(exec, s));
+        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, trace, trace_rows, s));
+    }
+    return MNX_OK;
+}
+
 int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
                       int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, float* token_logp, float* hidden,
                       float* logits_trace, void* stream) {
     if (!h) return MNX_ERR_INVALID_ARG;
     if (!features || !tokens || !lengths || B < 1) { h->err = "mnx_decode_greedy: null/empty argument"; return MNX_ERR_INVALID_ARG; }
-    if (B > MAX_ROWS || max_len < 1 || max_len > h->cfg.max_len) {
+    if (B > ROW_TILE || max_len < 1 || max_len > h->cfg.max_len) {
         h->err = "mnx_decode_greedy: B must be <= 32 and max_len <= cfg.max_len";
         return MNX_ERR_CAPACITY;
     }
@@ -554,56 +607,34 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
         s = h->own_stream;
     }
     const int S = h->db.S, D = c.dec_dim;
-    // enc_transform, then the cross-attention K/V of all layers in one SGEMM
+    // enc_transform, then the cross-attention K/V of all layers in one SGEMM (memory block i = row i)
     HIPCHK(h, launch_sgemm_tn(features, h->dw.w_enc, h->dw.b_enc, h->db.memory, B * S, D, h->dw.enc_dim, s));
     HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s));
-    HIPCHK(h, dec_enqueue_init(h->db, chunk_id, B, s));
+    HIPCHK(h, dec_enqueue_reset(h->db, s));
+    HIPCHK(h, dec_enqueue_admit_rows(h->db, chunk_id, B, max_len, stop_on_eos, s));
     float* trace = nullptr;
     if (logits_trace) {
         if (!h->out_trace) {
-            HIPCHK(h, hipMalloc((void**)&h->out_trace, (size_t)c.max_len * MAX_ROWS * c.vocab * 4));
+            HIPCHK(h, hipMalloc((void**)&h->out_trace, (size_t)c.max_len * ROW_TILE * c.vocab * 4));
             h->allocs.push_back(h->out_trace);
         }
         trace = h->out_trace;
     }
     hipGraphExec_t exec = nullptr;
-    if (h->use_graph) {
-        GraphKey key{B, max_len, stop_on_eos, trace ? 1 : 0};
-        auto it = h->graphs.find(key);
-        if (it == h->graphs.end()) {
-            hipGraph_t g = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            hipError_t e = dec_enqueue_step(h->dw, h->db, B, max_len, stop_on_eos, h->out_tokens, h->out_logp,
-                                            h->out_hidden, trace, s);
-            hipError_t e2 = hipStreamEndCapture(s, &g);
-            if (e != hipSuccess || e2 != hipSuccess) {
-                h->err = std::string("decode step capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-                return MNX_ERR_HIP;
-            }
-            HIPCHK(h, hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
-            hipGraphDestroy(g);
-            h->graphs[key] = exec;
-        } else {
-            exec = it->second;
-        }
-    }
+    int rc = get_tick_graph(h, ROW_TILE, trace, B, s, &exec);
+    if (rc != MNX_OK) return rc;
     const int poll = 8;
     for (int t = 0; t < max_len;) {
         const int n = std::min(poll, max_len - t);
-        for (int i = 0; i < n; ++i) {
-            if (exec) HIPCHK(h, hipGraphLaunch(exec, s));
-            else HIPCHK(h, dec_enqueue_step(h->dw, h->db, B, max_len, stop_on_eos, h->out_tokens, h->out_logp,
-                                            h->out_hidden, trace, s));
-        }
+        rc = run_ticks(h, exec, ROW_TILE, trace, B, n, s);
+        if (rc != MNX_OK) return rc;
         t += n;
-        HIPCHK(h, hipMemcpyAsync(h->host_flag, &h->db.st->n_alive, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, dec_enqueue_status(h->db, ROW_TILE, s));
+        HIPCHK(h, hipMemcpyAsync(h->host_flag, &h->db.st->n_active, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
         if (*h->host_flag == 0) break;
     }
-    HIPCHK(h, hipMemcpyAsync(tokens, h->out_tokens, (size_t)B * max_len * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(lengths, h->db.st->len, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    if (token_logp) HIPCHK(h, hipMemcpyAsync(token_logp, h->out_logp, (size_t)B * max_len * 4, hipMemcpyDeviceToDevice, s));
-    if (hidden) HIPCHK(h, hipMemcpyAsync(hidden, h->out_hidden, (size_t)B * max_len * D * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, gather_enqueue(h->db, nullptr, B, max_len, tokens, lengths, token_logp, hidden, s));
     if (logits_trace) HIPCHK(h, hipMemcpyAsync(logits_trace, trace, (size_t)max_len * B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));
     return MNX_OK;
@@ -616,10 +647,141 @@ int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const
         h->err = "mnx_edges: null/empty argument";
         return MNX_ERR_INVALID_ARG;
     }
-    if (B > MAX_ROWS || kmax > h->db.kmax) { h->err = "mnx_edges: B <= 32 and kmax <= cfg.max_atoms required"; return MNX_ERR_CAPACITY; }
+    if (B > ROW_TILE || kmax > h->db.kmax) { h->err = "mnx_edges: B <= 32 and kmax <= cfg.max_atoms required"; return MNX_ERR_CAPACITY; }
     HIPCHK(h, hipSetDevice(h->device));
-    DecBuffers bf = h->db;
-    HIPCHK(h, edges_enqueue(h->dw, bf, hidden, atom_idx, n_atoms, B, kmax, max_len, edges, scores, (hipStream_t)stream));
+    HIPCHK(h, edges_enqueue(h->dw, h->db, hidden, nullptr, atom_idx, n_atoms, B, kmax, max_len, edges, scores, (hipStream_t)stream));
+    return MNX_OK;
+}
+
+int mnx_set_token_classes(mnx_engine* h, const uint8_t* flags, int32_t n, int32_t lbracket, int32_t rbracket,
+                          int32_t id_C, int32_t id_l, int32_t id_B, int32_t id_r) {
+    if (!h || !flags || n < 1 || n > 256) return MNX_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    TokenClasses tc{};
+    memcpy(tc.flags, flags, (size_t)n);
+    tc.lbracket = lbracket; tc.rbracket = rbracket; tc.id_C = id_C; tc.id_l = id_l; tc.id_B = id_B; tc.id_r = id_r;
+    tc.x0 = h->cfg.sym_offset; tc.y0 = h->cfg.sym_offset + h->cfg.coord_bins; tc.vocab = h->cfg.vocab;
+    HIPCHK(h, hipMemcpy(h->tc_dev, &tc, sizeof(tc), hipMemcpyHostToDevice));
+    h->have_tc = true;
+    return MNX_OK;
+}
+
+int mnx_atom_scan(mnx_engine* h, const int32_t* tokens, const int32_t* lengths, int32_t n, int32_t T, int32_t kmax,
+                  int32_t* atom_idx, int32_t* n_atoms, void* stream) {
+    if (!h || !tokens || !lengths || !atom_idx || !n_atoms || n < 1 || T < 1 || kmax < 1) return MNX_ERR_INVALID_ARG;
+    if (!h->have_tc) { h->err = "mnx_atom_scan: call mnx_set_token_classes first"; return MNX_ERR_INVALID_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, atoms_enqueue_raw(h->tc_dev, tokens, lengths, n, T, kmax, atom_idx, n_atoms, (hipStream_t)stream));
+    return MNX_OK;
+}
+
+// The whole hot path for n_img images with continuous batching (see include/molnextr_hip.h).
+int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t max_len,
+                int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx, uint8_t* edges,
+                int32_t kmax, void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!images || !tokens || !lengths || !n_atoms || !atom_idx || !edges || n_img < 1) {
+        h->err = "mnx_predict: null/empty argument";
+        return MNX_ERR_INVALID_ARG;
+    }
+    if (!h->have_tc) { h->err = "mnx_predict: call mnx_set_token_classes first"; return MNX_ERR_INVALID_ARG; }
+    const mnx_config& c = h->cfg;
+    if (ref_batch < 1 || ref_batch > ROW_TILE || ref_batch > c.max_batch || max_len < 1 || max_len > c.max_len ||
+        kmax < 1 || kmax > h->db.kmax) {
+        h->err = "mnx_predict: ref_batch <= min(32, max_batch), max_len <= cfg.max_len, kmax <= cfg.max_atoms required";
+        return MNX_ERR_CAPACITY;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!s) {
+        if (!h->own_stream) HIPCHK(h, hipStreamCreate(&h->own_stream));
+        s = h->own_stream;
+    }
+    const int S = h->db.S, D = c.dec_dim, SL = MAX_SLOTS;
+    const size_t img_elems = (size_t)3 * c.img_size * c.img_size;
+    const int n_chunks = (n_img + ref_batch - 1) / ref_batch;
+    struct Chunk { int first, n, tag, admit_seq; std::vector<int> slots; };
+    std::vector<Chunk> live;
+    std::vector<int> free_slots;
+    for (int i = SL - 1; i >= 0; --i) free_slots.push_back(i);
+    std::vector<int> free_tags;
+    for (int i = h->n_chunk_bufs - 1; i >= 0; --i) free_tags.push_back(i);
+    int* pinned = h->host_flag;                       // [2][1 + MAX_CHUNKS] snapshots, then slot lists
+    int* pin_slots = h->host_flag + 2 * (1 + MAX_CHUNKS);
+    hipGraphExec_t exec = nullptr;
+    int rc = get_tick_graph(h, SL, nullptr, 0, s, &exec);
+    if (rc != MNX_OK) return rc;
+    HIPCHK(h, dec_enqueue_reset(h->db, s));
+    // the encoder stream must not start before the caller's stream reaches this point (images ready)
+    HIPCHK(h, hipEventRecord(h->ev_poll[0], s));
+    HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_poll[0], 0));
+    int next = 0, done = 0, seq = 0, fb = 0;
+    bool feat_used[2] = {false, false};
+    const int ticks_per_poll = 4;
+    while (done < n_chunks) {
+        // ---- admission: encode on the encoder stream, project the memory and admit on the decode stream
+        while (next < n_chunks && !free_tags.empty()) {
+            const int first = next * ref_batch, n = std::min(ref_batch, n_img - first);
+            if ((int)free_slots.size() < n) break;
+            Chunk ck;
+            ck.first = first; ck.n = n; ck.tag = free_tags.back(); ck.admit_seq = seq;
+            free_tags.pop_back();
+            for (int i = 0; i < n; ++i) { ck.slots.push_back(free_slots.back()); free_slots.pop_back(); }
+            if (feat_used[fb]) HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_feat_free[fb], 0));
+            rc = mnx_encode(h, images + (size_t)first * img_elems, n, h->feat_ring[fb], h->enc_stream);
+            if (rc != MNX_OK) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_enc_done[fb], h->enc_stream));
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_enc_done[fb], 0));
+            float* memkv = h->db.mem_kv + (size_t)ck.tag * ROW_TILE * S * c.dec_layers * 2 * D;
+            HIPCHK(h, launch_sgemm_tn(h->feat_ring[fb], h->dw.w_enc, h->dw.b_enc, h->db.memory, n * S, D, h->dw.enc_dim, s));
+            HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, memkv, n * S, c.dec_layers * 2 * D, D, s));
+            HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
+            feat_used[fb] = true;
+            fb ^= 1;
+            int* sl_dev = h->slot_lists + (size_t)ck.tag * ROW_TILE;
+            int* sl_pin = pin_slots + (size_t)ck.tag * ROW_TILE;     // pinned, private to this tag until it retires
+            for (int i = 0; i < n; ++i) sl_pin[i] = ck.slots[i];
+            HIPCHK(h, hipMemcpyAsync(sl_dev, sl_pin, (size_t)n * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(h, dec_enqueue_admit(h->db, sl_dev, nullptr, n, ck.tag, ck.tag * ROW_TILE, max_len, 1, s));
+            live.push_back(std::move(ck));
+            ++next;
+        }
+        // ---- a group of ticks, then a status snapshot
+        rc = run_ticks(h, exec, SL, nullptr, 0, ticks_per_poll, s);
+        if (rc != MNX_OK) return rc;
+        HIPCHK(h, dec_enqueue_status(h->db, SL, s));
+        int* snap = pinned + (seq & 1) * (1 + MAX_CHUNKS);
+        HIPCHK(h, hipMemcpyAsync(snap, &h->db.st->n_active, (size_t)(1 + MAX_CHUNKS) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipEventRecord(h->ev_poll[seq & 1], s));
+        // ---- retire chunks that the PREVIOUS snapshot shows finished (the GPU keeps ticking meanwhile)
+        if (seq > 0) {
+            const int ps = seq - 1;
+            HIPCHK(h, hipEventSynchronize(h->ev_poll[ps & 1]));
+            const int* sn = pinned + (ps & 1) * (1 + MAX_CHUNKS);
+            for (size_t i = 0; i < live.size();) {
+                Chunk& ck = live[i];
+                if (ck.admit_seq <= ps && sn[1 + ck.tag] == 0) {
+                    int* sl_dev = h->slot_lists + (size_t)ck.tag * ROW_TILE;
+                    int* o_idx = atom_idx + (size_t)ck.first * kmax;
+                    int* o_na = n_atoms + ck.first;
+                    HIPCHK(h, gather_enqueue(h->db, sl_dev, ck.n, max_len, tokens + (size_t)ck.first * max_len,
+                                             lengths + ck.first, nullptr, nullptr, s));
+                    HIPCHK(h, atoms_enqueue(h->db, h->tc_dev, sl_dev, ck.n, kmax, o_idx, o_na, s));
+                    HIPCHK(h, edges_enqueue(h->dw, h->db, h->db.hidden, sl_dev, o_idx, o_na, ck.n, kmax, h->db.T,
+                                            edges + (size_t)ck.first * kmax * kmax, nullptr, s));
+                    for (int sl : ck.slots) free_slots.push_back(sl);
+                    free_tags.push_back(ck.tag);
+                    live.erase(live.begin() + i);
+                    ++done;
+                } else {
+                    ++i;
+                }
+            }
+        }
+        ++seq;
+        if (seq > 200000) { h->err = "mnx_predict: watchdog (decode did not terminate)"; return MNX_ERR_HIP; }
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
     return MNX_OK;
 }
 

@@ -21,7 +21,7 @@ _lib = None
 ABI_VERSION = 1
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
-           "mnx_profile_read")
+           "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan")
 
 
 class MnxConfig(C.Structure):
@@ -79,6 +79,12 @@ def load_library():
     lib.mnx_profile_enable.argtypes = [vp, i32]
     lib.mnx_profile_read.restype = C.c_int
     lib.mnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.mnx_set_token_classes.restype = C.c_int
+    lib.mnx_set_token_classes.argtypes = [vp, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
+    lib.mnx_atom_scan.restype = C.c_int
+    lib.mnx_atom_scan.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.mnx_predict.restype = C.c_int
+    lib.mnx_predict.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
     if lib.mnx_abi_version() != ABI_VERSION:
         raise ImportError(f"libmolnextr_hip.so ABI {lib.mnx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
     _lib = lib
@@ -144,9 +150,19 @@ class Engine:
         if rc != 0:
             raise MnxError(f"mnx_create failed ({rc}): {self.lib.mnx_last_error(None).decode()}")
         self.h = handle
+        self._set_token_classes()
         self.n_feat = enc.num_features
         g = enc.img_size // enc.patch >> (len(enc.depths) - 1)
         self.n_mem = g * g
+
+    def _set_token_classes(self):
+        """Hands the vocabulary's token classes to the on-device atom-position scan (mnx_predict)."""
+        from .tokenizer import CharTokenizer
+        tok = CharTokenizer(64)
+        n = tok.offset
+        flags = bytes((1 if tok.is_symbol(i) else 0) | (2 if tok.is_atom(i) else 0) for i in range(n))
+        ids = [tok.stoi[c] for c in "[]ClBr"]
+        self._check(self.lib.mnx_set_token_classes(self.h, flags, n, *ids), "mnx_set_token_classes")
 
     def close(self):
         if getattr(self, "h", None):
@@ -214,6 +230,33 @@ class Engine:
                                 _ptr(scores), _stream())
         self._check(rc, "mnx_edges")
         return edges, scores
+
+    # -- whole path, continuous batching ----------------------------------------------------------
+    def predict(self, images: torch.Tensor, ref_batch: int = 32, max_len: Optional[int] = None) -> dict:
+        """Encoder + greedy decode + atom positions + bond head for all images (mnx_predict)."""
+        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        n = images.shape[0]
+        max_len = self.max_len if max_len is None else max_len
+        dev, k = images.device, self.max_atoms
+        tokens = torch.empty(n, max_len, dtype=torch.int32, device=dev)
+        lengths = torch.empty(n, dtype=torch.int32, device=dev)
+        n_atoms = torch.empty(n, dtype=torch.int32, device=dev)
+        atom_idx = torch.zeros(n, k, dtype=torch.int32, device=dev)
+        edges = torch.zeros(n, k, k, dtype=torch.uint8, device=dev)
+        rc = self.lib.mnx_predict(self.h, _ptr(images), n, ref_batch, max_len, _ptr(tokens), _ptr(lengths),
+                                  _ptr(n_atoms), _ptr(atom_idx), _ptr(edges), k, _stream())
+        self._check(rc, "mnx_predict")
+        return {"tokens": tokens, "lengths": lengths, "n_atoms": n_atoms, "atom_idx": atom_idx, "edges": edges}
+
+    def atom_scan(self, tokens: torch.Tensor, lengths: torch.Tensor, kmax: Optional[int] = None):
+        """On-device CharTokenizer.sequence_to_smiles 'indices' for [n,T] int32 id sequences."""
+        n, T = tokens.shape
+        kmax = kmax or self.max_atoms
+        idx = torch.zeros(n, kmax, dtype=torch.int32, device=tokens.device)
+        cnt = torch.zeros(n, dtype=torch.int32, device=tokens.device)
+        self._check(self.lib.mnx_atom_scan(self.h, _ptr(tokens), _ptr(lengths), n, T, kmax, _ptr(idx), _ptr(cnt),
+                                           _stream()), "mnx_atom_scan")
+        return idx, cnt
 
     def profile(self, enable: bool):
         self._check(self.lib.mnx_profile_enable(self.h, int(enable)), "mnx_profile_enable")

@@ -226,6 +226,81 @@ def test_end_to_end_predictions_vs_reference_golden(golden_dir, eng, dev):
         assert p["edges"] == g["edges"]
 
 
+def test_predict_pipeline_equals_per_batch_path(eng, dev):
+    """mnx_predict (continuous batching: rows of several reference batches resident at once, on-device atom scan)
+    must give, image by image, exactly what the per-batch API + host tokenizer give."""
+    from molnextr_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer()["chartok_coords"]
+    imgs = W.synthetic_images(80).to(dev)              # reference batches of 32: 32 + 32 + 16
+    out = eng.predict(imgs, ref_batch=32)
+    lens = out["lengths"].cpu().numpy()
+    toks = out["tokens"].cpu().numpy()
+    na = out["n_atoms"].cpu().numpy()
+    ai = out["atom_idx"].cpu().numpy()
+    ed = out["edges"].cpu().numpy()
+    for first in (0, 32, 64):
+        x = imgs[first:first + 32].contiguous()
+        feats = eng.encode(x)
+        ref = eng.decode_greedy(feats)
+        rl = ref["lengths"].cpu().numpy()
+        rt = ref["tokens"].cpu().numpy()
+        n = x.shape[0]
+        idx = torch.zeros(n, 160, dtype=torch.int32)
+        cnt = torch.zeros(n, dtype=torch.int32)
+        for b in range(n):
+            i = first + b
+            assert lens[i] == rl[b] and toks[i, :lens[i]].tolist() == rt[b, :rl[b]].tolist(), f"image {i}"
+            d = tok.sequence_to_smiles(rt[b, :rl[b]].tolist())
+            assert na[i] == len(d["indices"]) and ai[i, :na[i]].tolist() == d["indices"], f"image {i}: atom positions"
+            cnt[b] = len(d["indices"])
+            idx[b, :cnt[b]] = torch.tensor(d["indices"], dtype=torch.int32)
+        e, _ = eng.edges(ref["hidden"], idx.to(dev), cnt)
+        e = e.cpu().numpy()
+        for b in range(n):
+            k = int(cnt[b])
+            assert np.array_equal(ed[first + b, :k, :k], e[b, :k, :k]), f"image {first + b}: bonds"
+
+
+def test_device_atom_scan_vs_reference_golden_and_fuzz(golden_dir, eng, dev):
+    """The on-device restatement of sequence_to_smiles' 'indices': reference golden cases + a fuzz against the host
+    tokenizer (itself pinned by the same golden cases)."""
+    import random
+    from molnextr_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer()["chartok_coords"]
+    with open(os.path.join(golden_dir, "tokenizer.json")) as f:
+        seqs = [(c["ids"], c["out"]["indices"]) for c in json.load(f)["cases"] if len(c["ids"]) <= 480]
+    rng = random.Random(7)
+    s = tok.stoi
+    for _ in range(400):
+        seq = []
+        n = rng.randint(0, 200)
+        while len(seq) < n:
+            r = rng.random()
+            if r < 0.55:
+                sym = rng.choice(["C", "N", "O", "Cl", "Br", "[", "c", "*", "<unk>", "B", "Cr"])
+                if sym == "[":
+                    seq += [s["["], s[rng.choice("CNOH@+-23")], s[rng.choice("CNOH@+-23]")], s["]"]]
+                elif sym == "<unk>":
+                    seq.append(3)
+                else:
+                    seq += [s[c] for c in sym]
+                if rng.random() < 0.9:
+                    seq += [101 + rng.randint(0, 63), 165 + rng.randint(0, 63)]
+            else:
+                seq.append(rng.randint(0, 228))
+        seqs.append((seq, tok.sequence_to_smiles(seq)["indices"]))
+    T = 480
+    tokens = torch.zeros(len(seqs), T, dtype=torch.int32)
+    lengths = torch.zeros(len(seqs), dtype=torch.int32)
+    for i, (ids, _) in enumerate(seqs):
+        tokens[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+        lengths[i] = len(ids)
+    idx, cnt = eng.atom_scan(tokens.to(dev), lengths.to(dev))
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    for i, (ids, want) in enumerate(seqs):
+        assert cnt[i] == len(want) and idx[i, :cnt[i]].tolist() == want, (i, ids[:30])
+
+
 def test_capacity_and_argument_errors(eng, dev):
     from molnextr_amd.engine import MnxError
     with pytest.raises(MnxError, match="32"):
