@@ -48,6 +48,16 @@ def pack_records(tokens: np.ndarray, lengths: np.ndarray, atom_idx: np.ndarray, 
     return torch.from_numpy(rec)
 
 
+def pack_records_device(tokens: torch.Tensor, lengths: torch.Tensor, atom_idx: torch.Tensor, n_atoms: torch.Tensor,
+                        edges: torch.Tensor) -> torch.Tensor:
+    """Same record layout as pack_records, built on the device from the engine's output tensors
+    (tokens int32 [n,480], atom_idx int32 [n,kmax], edges uint8 [n,kmax,kmax]); no host round trip before the gather."""
+    n, kmax = atom_idx.shape
+    assert tokens.shape[1] == MAX_LEN and (kmax * kmax) % 4 == 0
+    e32 = edges.reshape(n, kmax * kmax).contiguous().view(torch.int32)
+    return torch.cat([lengths.view(n, 1), n_atoms.view(n, 1), tokens, atom_idx, e32], dim=1).contiguous()
+
+
 def unpack_records(rec: torch.Tensor, kmax: int) -> List[dict]:
     r = rec.cpu().numpy()
     out = []

@@ -41,6 +41,16 @@ def test_pack_unpack_round_trip():
         assert o["edges"] == edges[b, :n_atoms[b], :n_atoms[b]].astype(int).tolist()
 
 
+def test_device_packing_matches_host_packing():
+    kmax = 24
+    tokens, lengths, atom_idx, n_atoms, edges = _fake_results(0, 8, kmax)
+    # the engine zero-fills beyond lengths / n_atoms; host packing keeps whatever is passed: use identical inputs
+    a = shard.pack_records(tokens, lengths, atom_idx, n_atoms, edges, kmax)
+    b = shard.pack_records_device(torch.from_numpy(tokens), torch.from_numpy(lengths), torch.from_numpy(atom_idx),
+                                  torch.from_numpy(n_atoms), torch.from_numpy(edges))
+    assert torch.equal(a, b)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
