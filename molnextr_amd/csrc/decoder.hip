@@ -84,7 +84,7 @@ hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, fl
 // PRO: 0 plain input | 1 LayerNorm(gamma, beta, eps 1e-6) | 2 token embedding + row-PE, then LayerNorm
 // EPI: 0 q/k/v scatter (q scaled, k/v appended to the self cache at position t[slot])
 //      1 x[r, n] += result (residual, in place)   2 q-scale store   3 GELU store
-constexpr int TN = 8, XS = 260;
+constexpr int TN = 32, XS = 260;
 
 struct LinArgs {
     const float* in;      // [slots, K]      (PRO 2: unused)
@@ -104,20 +104,23 @@ struct LinArgs {
 
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[32 * XS];
+    // fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain) on a 32-row x 32-column tile; the 4 waves split K.
+    __shared__ __attribute__((aligned(16))) float xs[32 * XS];   // input slab; reused as the cross-wave reduction buffer
     __shared__ __attribute__((aligned(16))) float ws[TN * XS];
-    const int tid = threadIdx.x;
-    const int r = tid & 31, c = tid >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * TN;
     const int slot0 = blockIdx.y * ROW_TILE;
-    // LayerNorm / embedding thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
+    // LayerNorm / embedding / staging thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
     const int lrow = tid >> 3, part = tid & 7;
     const bool live = a.st->alive[slot0 + lrow] != 0;
     if (!__syncthreads_or(live)) return;            // whole tile idle
-    float acc = 0.f;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
     for (int k0 = 0; k0 < a.K; k0 += 256) {
-        // ---- stage the input slab [32, 256] and the weight tile [8, 256]: all loads first, then LDS stores ----
-        f32x4 xv[8], wv[2];
+        // ---- stage the input slab [32, 256] and the weight tile [32, 256]: all loads first, then LDS stores ----
+        f32x4 xv[8], wv[8];
         if (PRO == 2) {
             // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
             const float* e = a.emb + (size_t)a.st->prev_tok[slot0 + lrow] * 256 + part * 4;
@@ -132,10 +135,10 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
             for (int j = 0; j < 8; ++j)
                 xv[j] = live ? *(const f32x4*)(src + 32 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        {
+            const float* wsrc = a.W + (size_t)(n0 + lrow) * a.K + k0 + part * 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + 256 * j, nn = i >> 6, q = i & 63;
-            wv[j] = *(const f32x4*)(a.W + (size_t)(n0 + nn) * a.K + k0 + q * 4);
+            for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(wsrc + 32 * j);
         }
         if (PRO == 2 && blockIdx.x == 0 && live) {
 #pragma unroll
@@ -160,46 +163,66 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
                 xv[j] = xv[j] * rstd * *(const f32x4*)(a.gamma + part * 4 + 32 * j) +
                         *(const f32x4*)(a.beta + part * 4 + 32 * j);
         }
+        if (k0 > 0) __syncthreads();                 // previous chunk's fragment reads are done
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *(f32x4*)(xs + lrow * XS + part * 4 + 32 * j) = xv[j];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + 256 * j, nn = i >> 6, q = i & 63;
-            *(f32x4*)(ws + nn * XS + q * 4) = wv[j];
+        for (int j = 0; j < 8; ++j) {
+            *(f32x4*)(xs + lrow * XS + part * 4 + 32 * j) = xv[j];
+            *(f32x4*)(ws + lrow * XS + part * 4 + 32 * j) = wv[j];
         }
         __syncthreads();
-        const float* xr = xs + r * XS;
-        const float* wr = ws + c * XS;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 16
-        for (int k = 0; k < 256; k += 4) {
-            const f32x4 x4 = *(const f32x4*)(xr + k), w4 = *(const f32x4*)(wr + k);
-            a0 = fmaf(x4[0], w4[0], a0);
-            a1 = fmaf(x4[1], w4[1], a1);
-            a2 = fmaf(x4[2], w4[2], a2);
-            a3 = fmaf(x4[3], w4[3], a3);
+        // wave w owns k in [64w, 64w+64): per 16-k chunk one ds_read_b128 per operand tile feeds 4 MFMA k-steps
+        // (k-slot (step j, lane group g) <-> k = kb + 4g + j on BOTH operands, so the contraction is unchanged)
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int kb = wave * 64 + kc * 16 + fg * 4;
+            const f32x4 a0 = *(const f32x4*)(xs + (fr) * XS + kb), a1 = *(const f32x4*)(xs + (16 + fr) * XS + kb);
+            const f32x4 b0 = *(const f32x4*)(ws + (fr) * XS + kb), b1 = *(const f32x4*)(ws + (16 + fr) * XS + kb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
         }
-        acc += (a0 + a1) + (a2 + a3);
-        __syncthreads();
     }
-    const int slot = slot0 + r;
-    if (!a.st->alive[slot]) return;
-    const int n = n0 + c;
-    float v = acc + a.bias[n];
+    __syncthreads();
+    // cross-wave reduction through LDS: red[wave][row][col], D layout: lane holds rows fg*4+r, column fr
+    float* red = xs;                                  // 4 * 32 * 33 floats = 16.9 KB <= 33 KB
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * 32 + mt * 16 + fg * 4 + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
+    __syncthreads();
+    const int slot = slot0 + lrow;
+    if (!live) return;
+    const int nc = part * 4;                          // 4 consecutive output columns per thread
+    f32x4 v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        v[u] = (red[(0 * 32 + lrow) * 33 + nc + u] + red[(1 * 32 + lrow) * 33 + nc + u]) +
+               (red[(2 * 32 + lrow) * 33 + nc + u] + red[(3 * 32 + lrow) * 33 + nc + u]);
+    const int n = n0 + nc;
+    v += *(const f32x4*)(a.bias + n);
     if (EPI == 0) {
         const int part_ = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
         if (part_ == 0) {
-            a.out[(size_t)slot * 256 + ch] = v * 0.17677669529663687f;  // q / sqrt(32) before QK^T (onmt MHA)
+            *(f32x4*)(a.out + (size_t)slot * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
         } else {
             float* cache = part_ == 1 ? a.kcache : a.vcache;
-            cache[(((size_t)slot * a.heads + hd) * a.T + a.st->t[slot]) * 32 + d] = v;
+            *(f32x4*)(cache + (((size_t)slot * a.heads + hd) * a.T + a.st->t[slot]) * 32 + d) = v;
         }
     } else if (EPI == 1) {
-        a.out[(size_t)slot * a.N + n] += v;
+        float* o = a.out + (size_t)slot * a.N + n;
+        *(f32x4*)o = *(const f32x4*)o + v;
     } else if (EPI == 2) {
-        a.out[(size_t)slot * a.N + n] = v * 0.17677669529663687f;
+        *(f32x4*)(a.out + (size_t)slot * a.N + n) = v * 0.17677669529663687f;
     } else {
-        a.out[(size_t)slot * a.N + n] = gelu_erf(v);
+        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        *(f32x4*)(a.out + (size_t)slot * a.N + n) = v;
     }
 }
 
@@ -377,23 +400,17 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
 // Opens a tick: PE rank of every slot (rank among the alive slots of its chunk, by row index) and the alive
 // counters the host polls. One workgroup; the kernel boundary is the all-rows barrier.
 __global__ __launch_bounds__(256) void dec_begin_kernel(DecState* st, int slots) {
-    __shared__ int s_alive[MAX_SLOTS], s_chunk[MAX_SLOTS], s_rowc[MAX_SLOTS], s_cnt[MAX_CHUNKS];
+    __shared__ unsigned int s_mask[MAX_CHUNKS];     // bit r = row r of the chunk is alive (rows per chunk <= 32)
     const int tid = threadIdx.x;
-    if (tid < MAX_CHUNKS) s_cnt[tid] = 0;
+    if (tid < MAX_CHUNKS) s_mask[tid] = 0u;
     const int al = tid < slots ? st->alive[tid] : 0;
-    s_alive[tid] = al;
-    s_chunk[tid] = tid < slots ? st->chunk[tid] : -1;
-    s_rowc[tid] = tid < slots ? st->rowc[tid] : 0;
+    const int c = tid < slots ? (st->chunk[tid] & (MAX_CHUNKS - 1)) : 0;
+    const int rc = tid < slots ? (st->rowc[tid] & 31) : 0;
     __syncthreads();
-    if (al) {
-        const int c = s_chunk[tid], rc = s_rowc[tid];
-        int rank = 0;
-        for (int q = 0; q < slots; ++q) rank += (s_alive[q] != 0 && s_chunk[q] == c && s_rowc[q] < rc);
-        st->rank[tid] = rank;
-        atomicAdd(&s_cnt[c & (MAX_CHUNKS - 1)], 1);
-    }
+    if (al) atomicOr(&s_mask[c], 1u << rc);
     const int n = __syncthreads_count(al != 0);
-    if (tid < MAX_CHUNKS) st->chunk_alive[tid] = s_cnt[tid];
+    if (al) st->rank[tid] = __popc(s_mask[c] & ((1u << rc) - 1u));
+    if (tid < MAX_CHUNKS) st->chunk_alive[tid] = __popc(s_mask[tid]);
     if (tid == 0) { st->n_active = n; st->tick = st->tick + 1; }
 }
 
