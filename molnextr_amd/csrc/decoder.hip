@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
 
 // Opens a tick: PE rank of every slot (rank among the alive slots of its chunk, by row index) and the alive
 // counters the host polls. One workgroup; the kernel boundary is the all-rows barrier.
-__global__ __launch_bounds__(256) void dec_begin_kernel(DecState* st, int slots) {
+__global__ __launch_bounds__(MAX_SLOTS) void dec_begin_kernel(DecState* st, int slots) {
     __shared__ unsigned int s_mask[MAX_CHUNKS];     // bit r = row r of the chunk is alive (rows per chunk <= 32)
     const int tid = threadIdx.x;
     if (tid < MAX_CHUNKS) s_mask[tid] = 0u;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void dec_begin_kernel(DecState* st, int slots)
     if (tid == 0) { st->n_active = n; st->tick = st->tick + 1; }
 }
 
-__global__ void dec_reset_kernel(DecState* st) {
+__global__ __launch_bounds__(MAX_SLOTS) void dec_reset_kernel(DecState* st) {
     const int i = threadIdx.x;
     if (i == 0) { st->tick = 0; st->n_active = 0; }
     if (i < MAX_CHUNKS) st->chunk_alive[i] = 0;
@@ -441,12 +441,12 @@ static void lin(hipStream_t s, const LinArgs& a, int slots) {
 }
 
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s) {
-    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(256), 0, s, b.st, slots);
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st, slots);
     return hipGetLastError();
 }
 
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s) {
-    hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(256), 0, s, b.st);
+    hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st);
     return hipGetLastError();
 }
 
@@ -460,7 +460,7 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots, float* logits_trace,
                             int trace_rows, hipStream_t s) {
     const int D = 256, H = w.heads, T = b.T;
-    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(256), 0, s, b.st, slots);
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st, slots);
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& L = w.L[l];
         float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <time.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -440,7 +441,7 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->h16 = P.dalloc(MB * max_h * 2);
     DecBuffers& db = h->db;
     const int SL = MAX_SLOTS;
-    h->n_chunk_bufs = 24;
+    h->n_chunk_bufs = SL / ROW_TILE;   // one reference batch per 32-slot row tile
     db.T = c.max_len; db.S = (int)S; db.slots = SL; db.mem_blocks = h->n_chunk_bufs * ROW_TILE; db.kmax = c.max_atoms;
     db.st = (DecState*)P.dalloc(sizeof(DecState));
     db.x = (float*)P.dalloc((size_t)SL * D * 4);
@@ -463,13 +464,17 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->feat_ring[1] = (float*)P.dalloc((size_t)ROW_TILE * S * CF * 4);
     h->slot_lists = (int*)P.dalloc((size_t)MAX_CHUNKS * ROW_TILE * 4);
     h->tc_dev = (TokenClasses*)P.dalloc(sizeof(TokenClasses));
-    if (hipStreamCreateWithFlags(&h->enc_stream, hipStreamNonBlocking) != hipSuccess) P.problems.push_back("stream create failed");
+    {
+        int lo = 0, hi = 0;   // lowest priority for the encoder: decode ticks (tiny kernels) must not queue behind it
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->enc_stream, hipStreamNonBlocking, lo) != hipSuccess) P.problems.push_back("stream create failed");
+    }
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&h->ev_enc_done[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_feat_free[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_poll[i], hipEventDisableTiming) != hipSuccess)
             P.problems.push_back("event create failed");
-    if (hipHostMalloc((void**)&h->host_flag, 4096) != hipSuccess) P.problems.push_back("hipHostMalloc failed");
+    if (hipHostMalloc((void**)&h->host_flag, 16384) != hipSuccess) P.problems.push_back("hipHostMalloc failed");
 
     if (!P.problems.empty()) {
         g_create_error = "mnx_create: " + std::to_string(P.problems.size()) + " problem(s):";
@@ -702,9 +707,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     const int n_chunks = (n_img + ref_batch - 1) / ref_batch;
     struct Chunk { int first, n, tag, admit_seq; std::vector<int> slots; };
     std::vector<Chunk> live;
-    std::vector<int> free_slots;
-    for (int i = SL - 1; i >= 0; --i) free_slots.push_back(i);
-    std::vector<int> free_tags;
+    std::vector<int> free_tags;      // a chunk tag is also its 32-slot row tile and its memory K/V block
     for (int i = h->n_chunk_bufs - 1; i >= 0; --i) free_tags.push_back(i);
     int* pinned = h->host_flag;                       // [2][1 + MAX_CHUNKS] snapshots, then slot lists
     int* pin_slots = h->host_flag + 2 * (1 + MAX_CHUNKS);
@@ -715,29 +718,47 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     // the encoder stream must not start before the caller's stream reaches this point (images ready)
     HIPCHK(h, hipEventRecord(h->ev_poll[0], s));
     HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_poll[0], 0));
-    int next = 0, done = 0, seq = 0, fb = 0;
+    int next = 0, done = 0, seq = 0;
+    const char* trace_path = getenv("MNX_TRACE");
+    FILE* tf = trace_path ? fopen(trace_path, "a") : nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_begin = now_ms();
+    int next_enc = 0;                       // next chunk to hand to the encoder stream
+    int fb_chunk[2] = {-1, -1};             // chunk whose features sit (or are being produced) in feature buffer i
     bool feat_used[2] = {false, false};
     const int ticks_per_poll = 4;
     while (done < n_chunks) {
-        // ---- admission: encode on the encoder stream, project the memory and admit on the decode stream
-        while (next < n_chunks && !free_tags.empty()) {
-            const int first = next * ref_batch, n = std::min(ref_batch, n_img - first);
-            if ((int)free_slots.size() < n) break;
-            Chunk ck;
-            ck.first = first; ck.n = n; ck.tag = free_tags.back(); ck.admit_seq = seq;
-            free_tags.pop_back();
-            for (int i = 0; i < n; ++i) { ck.slots.push_back(free_slots.back()); free_slots.pop_back(); }
+        // ---- encoder prefetch: keep both feature buffers busy on the (low-priority) encoder stream
+        for (int fb = 0; fb < 2; ++fb) {
+            if (fb_chunk[fb] >= 0 || next_enc >= n_chunks) continue;
+            const int first = next_enc * ref_batch, n = std::min(ref_batch, n_img - first);
             if (feat_used[fb]) HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_feat_free[fb], 0));
             rc = mnx_encode(h, images + (size_t)first * img_elems, n, h->feat_ring[fb], h->enc_stream);
             if (rc != MNX_OK) return rc;
             HIPCHK(h, hipEventRecord(h->ev_enc_done[fb], h->enc_stream));
-            HIPCHK(h, hipStreamWaitEvent(s, h->ev_enc_done[fb], 0));
+            fb_chunk[fb] = next_enc++;
+        }
+        // ---- admission (in image order): only once the chunk's features are READY, so the decode stream never
+        //      waits for the encoder; project the memory and admit on the decode stream
+        while (next < n_chunks && !free_tags.empty()) {
+            const int fb = fb_chunk[0] == next ? 0 : (fb_chunk[1] == next ? 1 : -1);
+            if (fb < 0) break;
+            const int first = next * ref_batch, n = std::min(ref_batch, n_img - first);
+            const bool idle = live.empty();                          // nothing to decode: waiting is free
+            hipError_t q = idle ? hipEventSynchronize(h->ev_enc_done[fb]) : hipEventQuery(h->ev_enc_done[fb]);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) { h->err = std::string("encoder event: ") + hipGetErrorString(q); return MNX_ERR_HIP; }
+            Chunk ck;
+            ck.first = first; ck.n = n; ck.tag = free_tags.back(); ck.admit_seq = seq;
+            free_tags.pop_back();
+            for (int i = 0; i < n; ++i) ck.slots.push_back(ck.tag * ROW_TILE + i);
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_enc_done[fb], 0));   // already complete: ordering only
             float* memkv = h->db.mem_kv + (size_t)ck.tag * ROW_TILE * S * c.dec_layers * 2 * D;
             HIPCHK(h, launch_sgemm_tn(h->feat_ring[fb], h->dw.w_enc, h->dw.b_enc, h->db.memory, n * S, D, h->dw.enc_dim, s));
             HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, memkv, n * S, c.dec_layers * 2 * D, D, s));
             HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
             feat_used[fb] = true;
-            fb ^= 1;
+            fb_chunk[fb] = -1;
             int* sl_dev = h->slot_lists + (size_t)ck.tag * ROW_TILE;
             int* sl_pin = pin_slots + (size_t)ck.tag * ROW_TILE;     // pinned, private to this tag until it retires
             for (int i = 0; i < n; ++i) sl_pin[i] = ck.slots[i];
@@ -746,6 +767,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             live.push_back(std::move(ck));
             ++next;
         }
+        if (live.empty()) continue;       // (only possible before the first admission)
         // ---- a group of ticks, then a status snapshot
         rc = run_ticks(h, exec, SL, nullptr, 0, ticks_per_poll, s);
         if (rc != MNX_OK) return rc;
@@ -769,7 +791,6 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
                     HIPCHK(h, atoms_enqueue(h->db, h->tc_dev, sl_dev, ck.n, kmax, o_idx, o_na, s));
                     HIPCHK(h, edges_enqueue(h->dw, h->db, h->db.hidden, sl_dev, o_idx, o_na, ck.n, kmax, h->db.T,
                                             edges + (size_t)ck.first * kmax * kmax, nullptr, s));
-                    for (int sl : ck.slots) free_slots.push_back(sl);
                     free_tags.push_back(ck.tag);
                     live.erase(live.begin() + i);
                     ++done;
@@ -778,10 +799,13 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
                 }
             }
         }
+        if (tf) fprintf(tf, "%.3f seq %d live %zu next %d next_enc %d done %d free_tiles %zu\n", now_ms() - t_begin, seq,
+                        live.size(), next, next_enc, done, free_tags.size());
         ++seq;
         if (seq > 200000) { h->err = "mnx_predict: watchdog (decode did not terminate)"; return MNX_ERR_HIP; }
     }
     HIPCHK(h, hipStreamSynchronize(s));
+    if (tf) { fprintf(tf, "%.3f end\n", now_ms() - t_begin); fclose(tf); }
     return MNX_OK;
 }
 
