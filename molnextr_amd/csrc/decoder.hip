@@ -241,9 +241,13 @@ struct AttnArgs {
     int kstride, fixed_keys, heads, cross;
 };
 
-__global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
+    // 4 waves per (slot, head): the keys are split over all 256 lanes for the scores (one 128-byte key row per
+    // lane, all loads in flight at once) and over the 4 waves for P.V; partial results meet in LDS.
     __shared__ float ps[512];
-    const int lane = threadIdx.x;
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float po[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
     if (!a.st->alive[slot]) return;
     const int nkeys = a.cross ? a.fixed_keys : a.st->t[slot] + 1;
@@ -253,11 +257,11 @@ __global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
     f32x4 q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + (size_t)slot * 256 + hd * 32 + i * 4);
-    float sc[8];
+    float sc[2];
     float mx = -3.0e38f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int key = lane + j * 64;
+    for (int j = 0; j < 2; ++j) {
+        const int key = tid + j * 256;
         float s = -3.0e38f;
         if (key < nkeys) {
             const float* kp = Kb + (size_t)key * a.kstride;
@@ -276,22 +280,27 @@ __global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
         mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int key = lane + j * 64;
+    for (int j = 0; j < 2; ++j) {
+        const int key = tid + j * 256;
         const float p = key < nkeys ? expf(sc[j] - mx) : 0.f;
         ps[key] = p;
         sum += p;
     }
     sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
-    // P.V: lane = (key group kg = lane>>3, channel quad dq = lane&7); 8 keys per wave-load, independent loads
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    // P.V: wave w takes keys w*8 + kg + 32*i (kg = lane>>3), channel quad dq = lane&7: 32 keys per block-load
     const int kg = lane >> 3, dq = lane & 7;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    const int nk8 = (nkeys + 7) & ~7;
+    const int nk32 = (nkeys + 31) & ~31;
 #pragma unroll 4
-    for (int key = kg; key < nk8; key += 8) {
+    for (int key = wave * 8 + kg; key < nk32; key += 32) {
         const int kk = key < nkeys ? key : nkeys - 1;
         const f32x4 v = *(const f32x4*)(Vb + (size_t)kk * a.kstride + dq * 4);
         o += v * ps[key];       // ps[key] == 0 for key >= nkeys
@@ -302,7 +311,13 @@ __global__ __launch_bounds__(64) void dec_attn_kernel(AttnArgs a) {
         o[i] += __shfl_xor(o[i], 16, 64);
         o[i] += __shfl_xor(o[i], 32, 64);
     }
-    if (lane < 8) *(f32x4*)(a.ctx + (size_t)slot * 256 + hd * 32 + dq * 4) = o * (1.0f / sum);
+    if (lane < 8) *(f32x4*)(&po[wave][dq * 4]) = o;
+    __syncthreads();
+    if (tid < 8) {
+        const f32x4 r = (*(const f32x4*)&po[0][tid * 4] + *(const f32x4*)&po[1][tid * 4]) +
+                        (*(const f32x4*)&po[2][tid * 4] + *(const f32x4*)&po[3][tid * 4]);
+        *(f32x4*)(a.ctx + (size_t)slot * 256 + hd * 32 + tid * 4) = r * (1.0f / sum);
+    }
 }
 
 // =============================================================================================
@@ -474,7 +489,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots,
         AttnArgs at = {};
         at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
         at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32; at.fixed_keys = 0;
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(64), 0, s, at);
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(256), 0, s, at);
         // self final_linear + residual
         a.in = b.ctx; a.W = L.wo; a.bias = L.bo; a.out = b.x; a.N = D; a.K = D;
         lin<0, 1>(s, a, slots);
@@ -485,7 +500,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots,
         at.V = at.K + D;
         at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = 32; at.kstride = w.layers * 2 * D;
         at.fixed_keys = b.S; at.cross = 1;
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(64), 0, s, at);
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(256), 0, s, at);
         // context final_linear + residual
         a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = b.x;
         lin<0, 1>(s, a, slots);

@@ -16,24 +16,29 @@
 
 namespace mnx {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BK = 64;
 
 template <typename T>
 struct Stage {
     typename H16<T>::v8 a[4], w[4];
 };
+// BN = 128: 128x128 tile (64 KiB LDS, 2 workgroups/CU). BN = 64: 128x64 tile (48 KiB, 3 workgroups/CU) for
+// shapes whose 128x128 tile count does not fill the chip evenly (N <= 512 at stage 3/4).
 
 // byte offset of 16-byte chunk c (0..7) of tile row r in a [128][64] 16-bit LDS tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int BN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                       void* Cout, const float* __restrict__ bias,
                                                       const float* resid, int M, int N, int K, int tiles_n,
                                                       int n_tiles) {
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128][64] x 2 B = 64 KiB
+    constexpr int NT = BN / 32;          // 16-wide n-tiles per wave (waves are 2(M) x 2(N))
+    constexpr int WLD = BN / 32;         // W chunks per thread per K-tile
+    constexpr int STG = (BM + BN) * BK * 2;   // bytes per stage
+    __shared__ __attribute__((aligned(16))) char smem[2 * STG];  // [buf][A 128x64 | W BNx64] 16-bit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int tile = xcd_remap(blockIdx.x, n_tiles);
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
     const T* w_ptr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int ra = min(m0 + ld_r + 32 * i, M - 1), rw = min(n0 + ld_r + 32 * i, N - 1);
+        int ra = min(m0 + ld_r + 32 * i, M - 1), rw = min(n0 + ld_r + 32 * (i < WLD ? i : 0), N - 1);
         a_ptr[i] = A + (size_t)ra * K + ld_c * 8;
         w_ptr[i] = W + (size_t)rw * K + ld_c * 8;
     }
@@ -58,23 +63,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         for (int i = 0; i < 4; ++i) {
             v8 z = {};
             st.a[i] = ok ? *(const v8*)(a_ptr[i] + k0) : z;
-            st.w[i] = ok ? *(const v8*)(w_ptr[i] + k0) : z;
+            if (i < WLD) st.w[i] = ok ? *(const v8*)(w_ptr[i] + k0) : z;
         }
     };
     auto store_s = [&](int buf) {
-        char* ab = smem + buf * (2 * BM * BK * 2);
+        char* ab = smem + buf * STG;
         char* wb = ab + BM * BK * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = ld_r + 32 * i;
             *(v8*)(ab + lds_off(r, ld_c)) = st.a[i];
-            *(v8*)(wb + lds_off(r, ld_c)) = st.w[i];
+            if (i < WLD) *(v8*)(wb + lds_off(r, ld_c)) = st.w[i];
         }
     };
 
-    f32x4 acc[4][4];  // [nt][mt]
+    f32x4 acc[NT][4];  // [nt][mt]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -84,18 +89,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
     const int fr = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_g(kt + 1);
-        const char* ab = smem + (kt & 1) * (2 * BM * BK * 2);
+        const char* ab = smem + (kt & 1) * STG;
         const char* wb = ab + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            v8 af[4], wf[4];
+            v8 af[4], wf[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = *(const v8*)(ab + lds_off(wm * 64 + t * 16 + fr, ks * 4 + fg));
-                wf[t] = *(const v8*)(wb + lds_off(wn * 64 + t * 16 + fr, ks * 4 + fg));
-            }
+            for (int t = 0; t < 4; ++t) af[t] = *(const v8*)(ab + lds_off(wm * 64 + t * 16 + fr, ks * 4 + fg));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int t = 0; t < NT; ++t) wf[t] = *(const v8*)(wb + lds_off(wn * (BN / 2) + t * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
         }
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
 
     // epilogue: lane holds, per (nt,mt), row m = ..+fr and columns n = ..+fg*4 + {0,1,2,3}
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + fg * 4;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
         if (n >= N) continue;
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (bias) b4 = *(const f32x4*)(bias + n);
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
             f32x4 v = acc[nt][mt] + b4;
             const size_t o = (size_t)m * N + n;
             if (EPI == EPI_GELU_16) {
-                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
             }
             if (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16) {
                 v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
@@ -130,15 +134,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
     }
 }
 
-template <typename T>
-static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
-                           int M, int N, int K, hipStream_t s) {
+template <typename T, int BN>
+static hipError_t launch_bn(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
+                            int M, int N, int K, hipStream_t s) {
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
-#define MNX_GEMM_CASE(E)                                                                                         \
-    case E:                                                                                                      \
-        hipLaunchKernelGGL((gemm_tn_kernel<T, E>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid, \
-                           M, N, K, tn, tm * tn);                                                                \
+#define MNX_GEMM_CASE(E)                                                                                             \
+    case E:                                                                                                          \
+        hipLaunchKernelGGL((gemm_tn_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid, \
+                           M, N, K, tn, tm * tn);                                                                    \
         break;
     switch (epi) {
         MNX_GEMM_CASE(EPI_BIAS_16)
@@ -149,6 +153,18 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
     }
 #undef MNX_GEMM_CASE
     return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
+                           int M, int N, int K, hipStream_t s) {
+    // tile choice: 128x128 unless its tile count leaves the 512 resident-workgroup slots (256 CUs x 2) badly
+    // quantised; then 128x64 tiles (3 workgroups per CU)
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const double waves128 = (double)t128 / 512.0;
+    const bool small = t128 < 512 || (waves128 < 3.0 && (waves128 - (long)waves128) > 0.0 && (waves128 - (long)waves128) < 0.6);
+    if (small && N >= 64) return launch_bn<T, 64>(epi, A, W, C, bias, resid, M, N, K, s);
+    return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
 }
 
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
