@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--max-len", type=int, default=480)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="run the RCCL record gather even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,8 +147,8 @@ def main():
             stats["lens"], stats["atoms"] = np.array(lens), np.array(atoms)
             rec = torch.cat(recs).to(dev)
         if rec is not None:
-            if world > 1:       # result gather over xGMI: fixed-size records, one RCCL all-gather
-                rec = shard.gather_records(rec)
+            if world > 1 or args.force_gather:   # result gather over xGMI: fixed-size records, one RCCL all-gather
+                rec = shard.gather_records(rec, force=args.force_gather)
             rec = rec.cpu()
         return rec
 

@@ -11,6 +11,8 @@
 // global loads in flight under the MFMAs. The MFMA is issued "swapped" (A-operand = W rows, B-operand =
 // activation rows) so each lane ends up holding 4 CONSECUTIVE output columns of one row: the epilogue stores
 // 8-byte (16-bit out) or 16-byte (fp32 out) vectors and reads bias/residual as float4.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -27,6 +29,39 @@ struct Stage {
 
 // byte offset of 16-byte chunk c (0..7) of tile row r in a [128][64] 16-bit LDS tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// epilogue shared by both main-loop variants: lane holds, per (nt,mt), row m = ..+fr and 4 consecutive columns
+template <typename T, int EPI, int BN>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], void* Cout, const float* __restrict__ bias,
+                                              const float* resid, int M, int N, int m0, int n0, int wm, int wn, int fr,
+                                              int fg) {
+    typedef typename H16<T>::v4 v4;
+    constexpr int NT = BN / 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
+        if (n >= N) continue;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b4 = *(const f32x4*)(bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + fr;
+            if (m >= M) continue;
+            f32x4 v = acc[nt][mt] + b4;
+            const size_t o = (size_t)m * N + n;
+            if (EPI == EPI_GELU_16) {
+                v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
+            }
+            if (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16) {
+                v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                *(v4*)((T*)Cout + o) = o4;
+            } else {
+                if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
+                *(f32x4*)((float*)Cout + o) = v;
+            }
+        }
+    }
+}
 
 template <typename T, int EPI, int BN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ W,
@@ -107,31 +142,82 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         __syncthreads();
     }
 
-    // epilogue: lane holds, per (nt,mt), row m = ..+fr and columns n = ..+fg*4 + {0,1,2,3}
+    gemm_epilogue<T, EPI, BN>(acc, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
+}
+
+// Main-loop variant with direct global->LDS DMA (global_load_lds_dwordx4): no VGPR staging, no ds_write pass.
+// The LDS image written by a wave-instruction is lane-linear (base + lane*16 = 8 rows x 128 B), so the XOR swizzle
+// is applied on the per-lane SOURCE address and again on the fragment reads (same involution). Requires K % 64 == 0.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <typename T, int EPI, int BN>
+__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cout,
+                                                           const float* __restrict__ bias, const float* resid, int M,
+                                                           int N, int K, int tiles_n, int n_tiles) {
+    typedef typename H16<T>::v8 v8;
+    constexpr int NT = BN / 32;
+    constexpr int WLD = BN / 32;
+    constexpr int STG = (BM + BN) * BK * 2;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    // wave w fills A rows [32w, 32w+32) with 4 DMA instructions of 8 rows each, W rows [BN/4*w, ..) with WLD
+    const int r_in = lane >> 3, p = lane & 7;
+    const T* a_src[4];
+    const T* w_src[WLD];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
-        if (n >= N) continue;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (bias) b4 = *(const f32x4*)(bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wm * 64 + mt * 16 + fr;
-            if (m >= M) continue;
-            f32x4 v = acc[nt][mt] + b4;
-            const size_t o = (size_t)m * N + n;
-            if (EPI == EPI_GELU_16) {
-                v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
-            }
-            if (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16) {
-                v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                *(v4*)((T*)Cout + o) = o4;
-            } else {
-                if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
-                *(f32x4*)((float*)Cout + o) = v;
-            }
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + r_in;
+        a_src[i] = A + (size_t)min(m0 + r, M - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
     }
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+        const int r = (wave * WLD + i) * 8 + r_in;
+        w_src[i] = W + (size_t)min(n0 + r, N - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int kt, int buf) {
+        char* ab = smem + buf * STG;
+        char* wb = ab + BM * BK * 2;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + k0), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WLD; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + k0), (lds_void_t*)(wb + (wave * WLD + i) * 1024), 16, 0, 0);
+    };
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = K / BK;
+    issue(0, 0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* ab = smem + (kt & 1) * STG;
+        const char* wb = ab + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 af[4], wf[NT];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = *(const v8*)(ab + lds_off(wm * 64 + t * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *(const v8*)(wb + lds_off(wn * (BN / 2) + t * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
+        }
+        __syncthreads();   // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer kt&1 for tile kt+2
+    }
+    gemm_epilogue<T, EPI, BN>(acc, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
 
 template <typename T, int BN>
@@ -139,10 +225,15 @@ static hipError_t launch_bn(int epi, const void* A, const void* W, void* C, cons
                             int M, int N, int K, hipStream_t s) {
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
-#define MNX_GEMM_CASE(E)                                                                                             \
-    case E:                                                                                                          \
-        hipLaunchKernelGGL((gemm_tn_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid, \
-                           M, N, K, tn, tm * tn);                                                                    \
+    const bool glds = (K % BK) == 0 && getenv("MNX_NO_GLDS") == nullptr;
+#define MNX_GEMM_CASE(E)                                                                                                  \
+    case E:                                                                                                               \
+        if (glds)                                                                                                         \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias,    \
+                               resid, M, N, K, tn, tm * tn);                                                              \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gemm_tn_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid,  \
+                               M, N, K, tn, tm * tn);                                                                     \
         break;
     switch (epi) {
         MNX_GEMM_CASE(EPI_BIAS_16)

@@ -69,9 +69,9 @@ def unpack_records(rec: torch.Tensor, kmax: int) -> List[dict]:
     return out
 
 
-def gather_records(rec: torch.Tensor) -> torch.Tensor:
+def gather_records(rec: torch.Tensor, force: bool = False) -> torch.Tensor:
     """All-gather equal-sized [b, W] int32 records from every rank -> [world*b, W] (rank order = image order)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return rec
     world = dist.get_world_size()
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
