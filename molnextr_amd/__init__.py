@@ -8,3 +8,6 @@ The Encoder/Decoder forward runs in hand-written HIP kernels (csrc/) behind a C-
 __version__ = "0.1.0"
 
 from .tokenizer import CharTokenizer, get_tokenizer  # noqa: F401
+from .molnextr import MolNexTRSingleton, get_predictions  # noqa: F401
+
+__all__ = ["get_predictions", "MolNexTRSingleton", "CharTokenizer", "get_tokenizer"]

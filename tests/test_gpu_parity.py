@@ -301,6 +301,45 @@ def test_device_atom_scan_vs_reference_golden_and_fuzz(golden_dir, eng, dev):
         assert cnt[i] == len(want) and idx[i, :cnt[i]].tolist() == want, (i, ids[:30])
 
 
+def test_facade_reference_batch_size_semantics(eng, dev, synth_ckpt):
+    """decode_batch(ref_batch_size=16) must equal the reference run with batch_size=16 (its default in
+    predict_images): rows 0-15 and 16-31 are separate positional-encoding numberings."""
+    from molnextr_amd.model import decode_batch
+    from oracle.decoder import greedy_decode
+    feats = W.hash_normal("facade_features", (24, 144, 1024), 0.5)
+    preds = decode_batch(eng, feats.to(dev), ref_batch_size=16, compute_confidence=True, max_len=200)
+    ref = greedy_decode(feats[:16], synth_ckpt["decoder"], max_len=200).tokens + \
+        greedy_decode(feats[16:], synth_ckpt["decoder"], max_len=200).tokens
+    from molnextr_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer()["chartok_coords"]
+    for p, r in zip(preds, ref):
+        d = tok.sequence_to_smiles(r)
+        assert p["chartok_coords"]["smiles"] == d["smiles"] and p["chartok_coords"]["indices"] == d["indices"]
+        k = len(d["symbols"])
+        assert len(p["edges"]) == k and len(p["chartok_coords"]["atom_scores"]) == k
+        assert 0.0 <= p["overall_score"] <= 1.0
+        assert all(0.0 < s <= 1.0 for s in p["chartok_coords"]["atom_scores"])
+
+
+def test_public_api_predict_images_synthetic(dev):
+    """molnextr('synthetic').predict_images: reference output dict keys; no RDKit here -> SMILES fields None."""
+    from molnextr_amd.model import molnextr, BOND_TYPES
+    m = molnextr("synthetic", dev, max_batch=4)
+    img = np.full((120, 200, 3), 255, np.uint8)
+    img[40:80, 60:140] = 0
+    img[55:65, 20:180] = 30
+    out = m.predict_images([img, img[:, ::-1].copy()], return_atoms_bonds=True, return_confidence=True)
+    assert len(out) == 2
+    for o in out:
+        assert set(o) == {"predicted_smiles", "predicted_molfile", "atom_sets", "bond_sets"}
+        for a in o["atom_sets"]:
+            assert set(a) == {"atom_number", "atom_symbol", "coords", "confidence"}
+            assert 0.0 <= a["coords"][0] <= 1.0 and 0.0 <= a["coords"][1] <= 1.0
+        for b in o["bond_sets"]:
+            assert b["bond_type"] in BOND_TYPES[1:] and b["endpoints"][0] < b["endpoints"][1]
+    m.engine.close()
+
+
 def test_capacity_and_argument_errors(eng, dev):
     from molnextr_amd.engine import MnxError
     with pytest.raises(MnxError, match="32"):

@@ -39,3 +39,11 @@ for name, epi, M, N, K in shapes:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     print(f"{name:8s} epi{epi} M{M} N{N} K{K}: {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+if os.environ.get("CALIB"):
+    # known-byte-count calibration for FETCH_SIZE / WRITE_SIZE: a 512 MiB fp32 copy (read 512 MiB, write 512 MiB)
+    x = torch.randn(128 * 1024 * 1024, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    torch.cuda.synchronize()
+    print("calibration copy done: 536870912 bytes read, 536870912 bytes written per launch")
