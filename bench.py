@@ -60,6 +60,22 @@ def run_batch(eng, tok, images, kmax, max_len):
     return rec, lens, n_atoms
 
 
+def gemm_algorithmic_bytes(batch=BATCH):
+    """Average algorithmic HBM bytes per encoder GEMM launch (A + W read once, output written once, residual read
+    for the two residual epilogues) for Swin-B @384: the figure `roofline.traffic` is compared with."""
+    total, launches = 0, 0
+    for s, (L, C, depth) in enumerate([(9216, 128, 2), (2304, 256, 2), (576, 512, 18), (144, 1024, 2)]):
+        M = batch * L
+        per_block = [(M, 3 * C, C, 2, 0), (M, C, C, 4, 4), (M, 4 * C, C, 2, 0), (M, C, 4 * C, 4, 4)]
+        for (m, n, k, out_b, res_b) in per_block:
+            total += depth * (m * k * 2 + n * k * 2 + m * n * (out_b + res_b))
+            launches += depth
+        if s < 3:
+            total += (M // 4) * 4 * C * 2 + 2 * C * 4 * C * 2 + (M // 4) * 2 * C * 4
+            launches += 1
+    return total / launches
+
+
 def cpu_baseline(ck, seconds_budget=25.0):
     """Oracle on host cores: B=2 images through encoder + greedy decode + bond head, repeated within the budget."""
     from oracle.decoder import greedy_decode
@@ -183,9 +199,16 @@ def main():
         gemm_ms, gemm_flop, launches = eng.profile_read()
         eng.profile(False)
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        roofline = {"kernel": "mnx::gemm_tn_kernel (bf16 MFMA 16x16x32, all encoder Linear layers)",
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tpath):       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_traffic.py)
+            with open(tpath) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch"])
+            traffic_src = "profiles/r01_gemm_traffic.json (separate rocprofv3 --pmc passes over the same encoder launches)"
+        roofline = {"kernel": "mnx::gemm_tn_glds_kernel (bf16 MFMA 16x16x32, all encoder Linear layers)",
                     "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes()),
                     "launches": int(launches), "avg_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
                     "flop_per_launch_avg": round(gemm_flop / max(launches, 1))}
         cpu = None if args.no_cpu_baseline else cpu_baseline(ck)

@@ -2,6 +2,8 @@
 //
 // Activations are token-major [B, L, C] (= channels-last). The residual stream is fp32; the operands of the
 // MFMA GEMMs are produced here as 16-bit (bf16 by default).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -204,10 +206,11 @@ constexpr int WS = 12, WN = 144, HD = 32;
 constexpr int KS_STRIDE = 40;    // elements per K row in LDS (80 B: conflict-free ds_read_b128)
 constexpr int VT_STRIDE = 168;   // elements per V^T row in LDS (336 B: conflict-free ds_read_b64), keys 144..167 zero
 
-template <typename T>
-__global__ __launch_bounds__(192) void window_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
-                                                          T* __restrict__ out, int H, int W, int C, int heads,
-                                                          int shift) {
+template <typename T, int QT>   // QT query tiles (of 16) per wave; 9 / QT waves per workgroup
+__global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __restrict__ qkv,
+                                                                  const float* __restrict__ table, T* __restrict__ out,
+                                                                  int H, int W, int C, int heads, int shift) {
+    constexpr int NTHR = 64 * 9 / QT;
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
     __shared__ __attribute__((aligned(16))) T Ks[WN * KS_STRIDE];
@@ -223,19 +226,19 @@ __global__ __launch_bounds__(192) void window_attn_kernel(const T* __restrict__ 
     const int wy = bid % nWh;
     const int b = bid / nWh;
 
-    for (int t = tid; t < WN; t += 192) {
+    for (int t = tid; t < WN; t += NTHR) {
         int ys = wy * WS + t / WS, xs = wx * WS + t % WS;
         int yo = ys + shift; if (yo >= H) yo -= H;
         int xo = xs + shift; if (xo >= W) xo -= W;
         rowof[t] = (b * H + yo) * W + xo;
     }
-    for (int i = tid; i < 529; i += 192) tab[i] = table[i * heads + head];
-    for (int i = tid; i < HD * (VT_STRIDE - WN); i += 192)
+    for (int i = tid; i < 529; i += NTHR) tab[i] = table[i * heads + head];
+    for (int i = tid; i < HD * (VT_STRIDE - WN); i += NTHR)
         Vt[(i / (VT_STRIDE - WN)) * VT_STRIDE + WN + i % (VT_STRIDE - WN)] = (T)0.f;
     __syncthreads();
 
     const size_t ld = (size_t)3 * C;
-    for (int i = tid; i < WN * 4; i += 192) {       // 576 16-byte chunks each for K and V
+    for (int i = tid; i < WN * 4; i += NTHR) {       // 576 16-byte chunks each for K and V
         const int key = i >> 2, g8 = i & 3;
         const T* base = qkv + (size_t)rowof[key] * ld + head * HD + g8 * 8;
         const v8 kv = *(const v8*)(base + C);
@@ -245,32 +248,32 @@ __global__ __launch_bounds__(192) void window_attn_kernel(const T* __restrict__ 
         for (int j = 0; j < 8; ++j) Vt[(g8 * 8 + j) * VT_STRIDE + key] = vv[j];
     }
     const int fr = lane & 15, fg = lane >> 4;
-    v8 qf[3];
-    int qrow[3];
+    v8 qf[QT];
+    int qrow[QT];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        qrow[q] = rowof[(wave * 3 + q) * 16 + fr];
+    for (int q = 0; q < QT; ++q) {
+        qrow[q] = rowof[(wave * QT + q) * 16 + fr];
         qf[q] = *(const v8*)(qkv + (size_t)qrow[q] * ld + head * HD + fg * 8);
     }
     __syncthreads();
 
     // ---- S^T[key][query] -------------------------------------------------------------------
-    f32x4 acc[3][9];
+    f32x4 acc[QT][9];
 #pragma unroll
     for (int kt = 0; kt < 9; ++kt) {
         const v8 kf = *(const v8*)(Ks + (kt * 16 + fr) * KS_STRIDE + fg * 8);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < QT; ++q)
             acc[q][kt] = H16<T>::mfma(kf, qf[q], (f32x4){0.f, 0.f, 0.f, 0.f});
     }
 
     // ---- scale + relative-position bias + shift mask, softmax over keys ----------------------
     const float scale = 0.17677669529663687f;  // 32^-0.5 (reference scales q before QK^T; same product)
     const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
-    float inv_sum[3];
+    float inv_sum[QT];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int qi = (wave * 3 + q) * 16 + fr;
+    for (int q = 0; q < QT; ++q) {
+        const int qi = (wave * QT + q) * 16 + fr;
         const int qy = qi / WS, qx = qi % WS;
         const int rq = (last_y ? (qy < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (qx < WS - shift ? 1 : 2) : 0);
         float mx = -3.0e38f;
@@ -303,14 +306,14 @@ __global__ __launch_bounds__(192) void window_attn_kernel(const T* __restrict__ 
     }
 
     // ---- O^T[d][query] = V^T . P^T over 5 blocks of 32 key slots (last block half zero) -------
-    f32x4 oacc[3][2];
+    f32x4 oacc[QT][2];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) oacc[q][0] = oacc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < QT; ++q) oacc[q][0] = oacc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-        v8 pf[3];
+        v8 pf[QT];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < QT; ++q) {
             const f32x4 lo = acc[q][2 * m];
             const f32x4 hi = (m < 4) ? acc[q][m < 4 ? 2 * m + 1 : 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
             pf[q] = (v8){(T)lo[0], (T)lo[1], (T)lo[2], (T)lo[3], (T)hi[0], (T)hi[1], (T)hi[2], (T)hi[3]};
@@ -321,11 +324,11 @@ __global__ __launch_bounds__(192) void window_attn_kernel(const T* __restrict__ 
             const v4 a = *(const v4*)vrow, c = *(const v4*)(vrow + 16);
             const v8 vf = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
 #pragma unroll
-            for (int q = 0; q < 3; ++q) oacc[q][dt] = H16<T>::mfma(vf, pf[q], oacc[q][dt]);
+            for (int q = 0; q < QT; ++q) oacc[q][dt] = H16<T>::mfma(vf, pf[q], oacc[q][dt]);
         }
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < QT; ++q)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const f32x4 o = oacc[q][dt] * inv_sum[q];
@@ -337,13 +340,14 @@ __global__ __launch_bounds__(192) void window_attn_kernel(const T* __restrict__ 
 hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,
                               int C, int heads, int shift, hipStream_t s) {
     if (C != heads * HD || H % WS || W % WS) return hipErrorInvalidValue;
-    dim3 grid(B * (H / WS) * (W / WS) * heads), block(192);
-    if (dtype == MNX_DT_F16)
-        hipLaunchKernelGGL((window_attn_kernel<f16_t>), grid, block, 0, s, (const f16_t*)qkv16, rel_table,
-                           (f16_t*)out16, H, W, C, heads, shift);
-    else
-        hipLaunchKernelGGL((window_attn_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)qkv16, rel_table,
-                           (bf16_t*)out16, H, W, C, heads, shift);
+    static const int qt = getenv("MNX_ATTN_QT") ? atoi(getenv("MNX_ATTN_QT")) : 1;
+    dim3 grid(B * (H / WS) * (W / WS) * heads);
+#define MNX_ATTN(TT, Q)                                                                                              \
+    hipLaunchKernelGGL((window_attn_kernel<TT, Q>), grid, dim3(64 * 9 / Q), 0, s, (const TT*)qkv16, rel_table,      \
+                       (TT*)out16, H, W, C, heads, shift)
+    if (dtype == MNX_DT_F16) { if (qt == 3) MNX_ATTN(f16_t, 3); else MNX_ATTN(f16_t, 1); }
+    else { if (qt == 3) MNX_ATTN(bf16_t, 3); else MNX_ATTN(bf16_t, 1); }
+#undef MNX_ATTN
     return hipGetLastError();
 }
 
