@@ -18,6 +18,8 @@
 
 namespace mnx {
 
+__device__ int g_ablate = 0;   // experiment knob (tools only): 1 = skip epilogue stores, 2 = skip epilogue math+stores
+
 constexpr int BM = 128, BK = 64;
 
 template <typename T>
@@ -30,36 +32,79 @@ struct Stage {
 // byte offset of 16-byte chunk c (0..7) of tile row r in a [128][64] 16-bit LDS tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
-// epilogue shared by both main-loop variants: lane holds, per (nt,mt), row m = ..+fr and 4 consecutive columns
+// Epilogue shared by both main-loop variants. The MFMA accumulators hold, per lane, 4 consecutive columns of 16 different
+// rows — stored directly that is 8-byte pieces of 32-byte row segments, and an ablation showed those stores cost
+// 25-55 % of the kernel on the wide outputs. So the tile is transposed through LDS (free after the K loop) and written
+// as whole 128-byte lines, 16 bytes per lane; the residual (fp32, in place) is read in the same coalesced pattern.
 template <typename T, int EPI, int BN>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], void* Cout, const float* __restrict__ bias,
-                                              const float* resid, int M, int N, int m0, int n0, int wm, int wn, int fr,
-                                              int fg) {
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* smem, void* Cout,
+                                              const float* __restrict__ bias, const float* resid, int M, int N, int m0,
+                                              int n0, int wm, int wn, int fr, int fg) {
     typedef typename H16<T>::v4 v4;
+    typedef typename H16<T>::v8 v8;
     constexpr int NT = BN / 32;
+    constexpr bool OUT16 = (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16);
+    constexpr int ELT = OUT16 ? 2 : 4;
+    constexpr int ROWB = BN * ELT + 16;                  // padded LDS row (bytes)
+    constexpr int CH_ROW = BN * ELT / 16;                // 16-byte chunks per output row
+    const int tid = threadIdx.x;
+    const int ablate = g_ablate;
+    if (ablate == 2) {
+        float s = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
-        if (n >= N) continue;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (bias) b4 = *(const f32x4*)(bias + n);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wm * 64 + mt * 16 + fr;
-            if (m >= M) continue;
-            f32x4 v = acc[nt][mt] + b4;
-            const size_t o = (size_t)m * N + n;
-            if (EPI == EPI_GELU_16) {
-                v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
-            }
-            if (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16) {
-                v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                *(v4*)((T*)Cout + o) = o4;
-            } else {
-                if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
-                *(f32x4*)((float*)Cout + o) = v;
+            for (int mt = 0; mt < 4; ++mt) s += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
+        if (s == 12345.678f) ((float*)Cout)[0] = s;
+        return;
+    }
+    // fp32 tiles of 128x128 do not fit the staging area at once: two passes of 64 rows (one per wave row wm)
+    constexpr int PASSES = (!OUT16 && BN == 128) ? 2 : 1;
+    constexpr int ROWS = BM / PASSES;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (PASSES == 1 || wm == pass) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nl = wn * (BN / 2) + nt * 16 + fg * 4;
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (bias && n0 + nl < N) b4 = *(const f32x4*)(bias + n0 + nl);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int ml = (PASSES == 1 ? wm * 64 : 0) + mt * 16 + fr;
+                    f32x4 v = acc[nt][mt] + b4;
+                    if (EPI == EPI_GELU_16) {
+                        v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
+                    }
+                    if (OUT16) {
+                        v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                        *(v4*)(smem + ml * ROWB + nl * 2) = o4;
+                    } else {
+                        *(f32x4*)(smem + ml * ROWB + nl * 4) = v;
+                    }
+                }
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ROWS * CH_ROW / 256; ++i) {
+            const int id = tid + i * 256;
+            const int rl = id / CH_ROW, ch = id % CH_ROW;
+            const int m = m0 + pass * ROWS + rl;
+            const int n = n0 + ch * (16 / ELT);
+            if (m < M && n < N) {
+                const size_t o = (size_t)m * N + n;
+                if (OUT16) {
+                    const v8 v = *(const v8*)(smem + rl * ROWB + ch * 16);
+                    if (ablate != 1) *(v8*)((T*)Cout + o) = v;
+                } else {
+                    f32x4 v = *(const f32x4*)(smem + rl * ROWB + ch * 16);
+                    if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
+                    if (ablate != 1) *(f32x4*)((float*)Cout + o) = v;
+                }
+            }
+        }
+        if (PASSES > 1) __syncthreads();
     }
 }
 
@@ -142,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         __syncthreads();
     }
 
-    gemm_epilogue<T, EPI, BN>(acc, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
+    gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
 
 // Main-loop variant with direct global->LDS DMA (global_load_lds_dwordx4): no VGPR staging, no ds_write pass.
@@ -217,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
         }
         __syncthreads();   // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer kt&1 for tile kt+2
     }
-    gemm_epilogue<T, EPI, BN>(acc, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
+    gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
 
 template <typename T, int BN>
@@ -258,9 +303,11 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
     return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
 }
 
+void set_gemm_ablate(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &v, sizeof(int)); }
+
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                          const float* resid, int M, int N, int K, hipStream_t s) {
-    if ((K & 7) || (N & 3) || M <= 0) return hipErrorInvalidValue;
+    if ((K & 7) || (N & 7) || M <= 0) return hipErrorInvalidValue;
     return dtype == MNX_DT_F16 ? launch_t<f16_t>(epi, A, W, C, bias, resid, M, N, K, s)
                                : launch_t<bf16_t>(epi, A, W, C, bias, resid, M, N, K, s);
 }
