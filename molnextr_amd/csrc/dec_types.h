@@ -28,6 +28,7 @@ struct DecState {
     int mem_blk[MAX_SLOTS];        // which 144-row block of mem_kv holds this slot's cross-attention K/V
     int max_len[MAX_SLOTS];
     int stop_on_eos[MAX_SLOTS];
+    int active[MAX_SLOTS];         // compact list of the alive slots for the current tick (rows 0..n_active-1)
 };
 
 struct DecLayerW {
@@ -74,7 +75,7 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
                              int mem_blk0, int max_len, int stop_on_eos, hipStream_t s);
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s);
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s);
-hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots, float* logits_trace,
+hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
                             int trace_rows, hipStream_t s);
 hipError_t dec_enqueue_admit_rows(const DecBuffers& b, const int* chunk_ids_dev, int n, int max_len, int stop_on_eos,
                                   hipStream_t s);

@@ -109,11 +109,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     __shared__ __attribute__((aligned(16))) float ws[TN * XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * TN;
-    const int slot0 = blockIdx.y * ROW_TILE;
+    const int row0 = blockIdx.y * ROW_TILE;          // rows are positions in the tick's compact active list
+    const int n_act = a.st->n_active;
+    if (row0 >= n_act) return;                       // whole tile idle
     // LayerNorm / embedding / staging thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
     const int lrow = tid >> 3, part = tid & 7;
-    const bool live = a.st->alive[slot0 + lrow] != 0;
-    if (!__syncthreads_or(live)) return;            // whole tile idle
+    const bool live = row0 + lrow < n_act;
+    const int lslot = live ? a.st->active[row0 + lrow] : 0;
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -123,14 +125,14 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
         f32x4 xv[8], wv[8];
         if (PRO == 2) {
             // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
-            const float* e = a.emb + (size_t)a.st->prev_tok[slot0 + lrow] * 256 + part * 4;
-            const float* p = a.pe + (size_t)a.st->rank[slot0 + lrow] * 256 + part * 4;
+            const float* e = a.emb + (size_t)a.st->prev_tok[lslot] * 256 + part * 4;
+            const float* p = a.pe + (size_t)a.st->rank[lslot] * 256 + part * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 xv[j] = live ? *(const f32x4*)(e + 32 * j) * 16.0f + *(const f32x4*)(p + 32 * j)
                              : (f32x4){0.f, 0.f, 0.f, 0.f};
         } else {
-            const float* src = a.in + (size_t)(slot0 + lrow) * a.K + k0 + part * 4;
+            const float* src = a.in + (size_t)(row0 + lrow) * a.K + k0 + part * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 xv[j] = live ? *(const f32x4*)(src + 32 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
         }
         if (PRO == 2 && blockIdx.x == 0 && live) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *(f32x4*)(a.x_write + (size_t)(slot0 + lrow) * 256 + part * 4 + 32 * j) = xv[j];
+            for (int j = 0; j < 8; ++j) *(f32x4*)(a.x_write + (size_t)(row0 + lrow) * 256 + part * 4 + 32 * j) = xv[j];
         }
         if (PRO != 0) {  // LayerNorm in registers: 8 lanes per row, two-pass (K == 256)
             float s = 0.f;
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
             for (int r = 0; r < 4; ++r)
                 red[(wave * 32 + mt * 16 + fg * 4 + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
     __syncthreads();
-    const int slot = slot0 + lrow;
+    const int slot = lslot;                           // persistent state (caches) is per slot,
+    const int row = row0 + lrow;                      // activations of this tick are per active-list row
     if (!live) return;
     const int nc = part * 4;                          // 4 consecutive output columns per thread
     f32x4 v;
@@ -210,19 +213,19 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     if (EPI == 0) {
         const int part_ = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
         if (part_ == 0) {
-            *(f32x4*)(a.out + (size_t)slot * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
+            *(f32x4*)(a.out + (size_t)row * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
         } else {
             float* cache = part_ == 1 ? a.kcache : a.vcache;
             *(f32x4*)(cache + (((size_t)slot * a.heads + hd) * a.T + a.st->t[slot]) * 32 + d) = v;
         }
     } else if (EPI == 1) {
-        float* o = a.out + (size_t)slot * a.N + n;
+        float* o = a.out + (size_t)row * a.N + n;
         *(f32x4*)o = *(const f32x4*)o + v;
     } else if (EPI == 2) {
-        *(f32x4*)(a.out + (size_t)slot * a.N + n) = v * 0.17677669529663687f;
+        *(f32x4*)(a.out + (size_t)row * a.N + n) = v * 0.17677669529663687f;
     } else {
         v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-        *(f32x4*)(a.out + (size_t)slot * a.N + n) = v;
+        *(f32x4*)(a.out + (size_t)row * a.N + n) = v;
     }
 }
 
@@ -248,15 +251,16 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float po[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
-    if (!a.st->alive[slot]) return;
+    const int row = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
+    if (row >= a.st->n_active) return;
+    const int slot = a.st->active[row];
     const int nkeys = a.cross ? a.fixed_keys : a.st->t[slot] + 1;
     const long long rowb = a.cross ? (long long)a.st->mem_blk[slot] : (long long)slot;
     const float* Kb = a.K + rowb * a.row_stride + hd * a.head_stride;
     const float* Vb = a.V + rowb * a.row_stride + hd * a.head_stride;
     f32x4 q[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + (size_t)slot * 256 + hd * 32 + i * 4);
+    for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + (size_t)row * 256 + hd * 32 + i * 4);
     float sc[2];
     float mx = -3.0e38f;
 #pragma unroll
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     if (tid < 8) {
         const f32x4 r = (*(const f32x4*)&po[0][tid * 4] + *(const f32x4*)&po[1][tid * 4]) +
                         (*(const f32x4*)&po[2][tid * 4] + *(const f32x4*)&po[3][tid * 4]);
-        *(f32x4*)(a.ctx + (size_t)slot * 256 + hd * 32 + tid * 4) = r * (1.0f / sum);
+        *(f32x4*)(a.ctx + (size_t)row * 256 + hd * 32 + tid * 4) = r * (1.0f / sum);
     }
 }
 
@@ -345,11 +349,12 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __shared__ float red[8];
     __shared__ int redi[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = blockIdx.x;
-    if (!a.st->alive[slot]) return;
+    const int row = blockIdx.x;
+    if (row >= a.st->n_active) return;
+    const int slot = a.st->active[row];
     const int t = a.st->t[slot];
     if (wave == 0) {
-        f32x4 v = *(const f32x4*)(a.x + (size_t)slot * 256 + lane * 4);
+        f32x4 v = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
         v -= mean;
         const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
@@ -416,17 +421,28 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
 // counters the host polls. One workgroup; the kernel boundary is the all-rows barrier.
 __global__ __launch_bounds__(MAX_SLOTS) void dec_begin_kernel(DecState* st, int slots) {
     __shared__ unsigned int s_mask[MAX_CHUNKS];     // bit r = row r of the chunk is alive (rows per chunk <= 32)
-    const int tid = threadIdx.x;
+    __shared__ int s_wave[MAX_SLOTS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < MAX_CHUNKS) s_mask[tid] = 0u;
     const int al = tid < slots ? st->alive[tid] : 0;
     const int c = tid < slots ? (st->chunk[tid] & (MAX_CHUNKS - 1)) : 0;
     const int rc = tid < slots ? (st->rowc[tid] & 31) : 0;
+    // compact list of alive slots, in slot order (ballot prefix per wave + wave offsets)
+    const unsigned long long bal = __ballot(al != 0);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
     __syncthreads();
     if (al) atomicOr(&s_mask[c], 1u << rc);
-    const int n = __syncthreads_count(al != 0);
+    int base = 0, total = 0;
+    for (int w = 0; w < MAX_SLOTS / 64; ++w) {
+        const int cw = s_wave[w];
+        if (w < wave) base += cw;
+        total += cw;
+    }
+    if (al) st->active[base + __popcll(bal & ((1ull << lane) - 1ull))] = tid;
+    __syncthreads();
     if (al) st->rank[tid] = __popc(s_mask[c] & ((1u << rc) - 1u));
     if (tid < MAX_CHUNKS) st->chunk_alive[tid] = __popc(s_mask[tid]);
-    if (tid == 0) { st->n_active = n; st->tick = st->tick + 1; }
+    if (tid == 0) { st->n_active = total; st->tick = st->tick + 1; }
 }
 
 __global__ __launch_bounds__(MAX_SLOTS) void dec_reset_kernel(DecState* st) {
@@ -472,10 +488,13 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
     return hipGetLastError();
 }
 
-hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots, float* logits_trace,
+hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
                             int trace_rows, hipStream_t s) {
+    // slots_scan: state slots the begin kernel scans; rows: capacity of the compact active list this tick is
+    // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
     const int D = 256, H = w.heads, T = b.T;
-    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st, slots);
+    const int slots = rows;
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st, slots_scan);
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& L = w.L[l];
         float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;

@@ -36,8 +36,8 @@ struct StageW {
     int C = 0, heads = 0;
 };
 struct GraphKey {
-    int slots, trace;
-    bool operator<(const GraphKey& o) const { return std::tie(slots, trace) < std::tie(o.slots, o.trace); }
+    int slots, rows, trace;
+    bool operator<(const GraphKey& o) const { return std::tie(slots, rows, trace) < std::tie(o.slots, o.rows, o.trace); }
 };
 
 }  // namespace
@@ -587,16 +587,17 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     return MNX_OK;
 }
 
-static int get_tick_graph(mnx_engine* h, int slots, float* trace, int trace_rows, hipStream_t s, hipGraphExec_t* out) {
+static int get_tick_graph(mnx_engine* h, int slots, int rows, float* trace, int trace_rows, hipStream_t s,
+                          hipGraphExec_t* out) {
     *out = nullptr;
     if (!h->use_graph) return MNX_OK;
-    GraphKey key{slots, trace ? trace_rows : 0};
+    GraphKey key{slots, rows, trace ? trace_rows : 0};
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { *out = it->second; return MNX_OK; }
     hipGraph_t g = nullptr;
     hipGraphExec_t exec = nullptr;
     HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, trace, trace_rows, s);
+    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s);
     hipError_t e2 = hipStreamEndCapture(s, &g);
     if (e != hipSuccess || e2 != hipSuccess) {
         h->err = std::string("decode tick capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
@@ -609,10 +610,11 @@ static int get_tick_graph(mnx_engine* h, int slots, float* trace, int trace_rows
     return MNX_OK;
 }
 
-static int run_ticks(mnx_engine* h, hipGraphExec_t exec, int slots, float* trace, int trace_rows, int n, hipStream_t s) {
+static int run_ticks(mnx_engine* h, hipGraphExec_t exec, int slots, int rows, float* trace, int trace_rows, int n,
+                     hipStream_t s) {
     for (int i = 0; i < n; ++i) {
         if (exec) HIPCHK(h, hipGraphLaunch(exec, s));
-        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, trace, trace_rows, s));
+        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s));
     }
     return MNX_OK;
 }
@@ -648,12 +650,12 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
         trace = h->out_trace;
     }
     hipGraphExec_t exec = nullptr;
-    int rc = get_tick_graph(h, ROW_TILE, trace, B, s, &exec);
+    int rc = get_tick_graph(h, ROW_TILE, ROW_TILE, trace, B, s, &exec);
     if (rc != MNX_OK) return rc;
     const int poll = 8;
     for (int t = 0; t < max_len;) {
         const int n = std::min(poll, max_len - t);
-        rc = run_ticks(h, exec, ROW_TILE, trace, B, n, s);
+        rc = run_ticks(h, exec, ROW_TILE, ROW_TILE, trace, B, n, s);
         if (rc != MNX_OK) return rc;
         t += n;
         HIPCHK(h, dec_enqueue_status(h->db, ROW_TILE, s));
@@ -738,9 +740,9 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     for (int i = h->n_chunk_bufs - 1; i >= 0; --i) free_tags.push_back(i);
     int* pinned = h->host_flag;                       // [2][1 + MAX_CHUNKS] snapshots, then slot lists
     int* pin_slots = h->host_flag + 2 * (1 + MAX_CHUNKS);
-    hipGraphExec_t exec = nullptr;
-    int rc = get_tick_graph(h, SL, nullptr, 0, s, &exec);
-    if (rc != MNX_OK) return rc;
+    int rc = MNX_OK;
+    int bound = 0;                                    // upper bound of alive rows (host-side, conservative)
+    std::vector<std::pair<int, int>> admits;          // (iteration, rows) of every admission
     HIPCHK(h, dec_enqueue_reset(h->db, s));
     // the encoder stream must not start before the caller's stream reaches this point (images ready)
     HIPCHK(h, hipEventRecord(h->ev_poll[0], s));
@@ -791,12 +793,21 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             for (int i = 0; i < n; ++i) sl_pin[i] = ck.slots[i];
             HIPCHK(h, hipMemcpyAsync(sl_dev, sl_pin, (size_t)n * 4, hipMemcpyHostToDevice, s));
             HIPCHK(h, dec_enqueue_admit(h->db, sl_dev, nullptr, n, ck.tag, ck.tag * ROW_TILE, max_len, 1, s));
+            bound += n;
+            admits.emplace_back(seq, n);
             live.push_back(std::move(ck));
             ++next;
         }
         if (live.empty()) continue;       // (only possible before the first admission)
         // ---- a group of ticks, then a status snapshot
-        rc = run_ticks(h, exec, SL, nullptr, 0, ticks_per_poll, s);
+        // launch the tick graph sized for the alive-row bound (dense active list: idle row tiles are not launched)
+        static const int caps[] = {64, 128, 192, 256, 384, 512, 768, 1024};
+        int rows_cap = SL;
+        for (int cp : caps) if (cp >= bound) { rows_cap = cp; break; }
+        hipGraphExec_t exec = nullptr;
+        rc = get_tick_graph(h, SL, rows_cap, nullptr, 0, s, &exec);
+        if (rc != MNX_OK) return rc;
+        rc = run_ticks(h, exec, SL, rows_cap, nullptr, 0, ticks_per_poll, s);
         if (rc != MNX_OK) return rc;
         HIPCHK(h, dec_enqueue_status(h->db, SL, s));
         int* snap = pinned + (seq & 1) * (1 + MAX_CHUNKS);
@@ -807,6 +818,12 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             const int ps = seq - 1;
             HIPCHK(h, hipEventSynchronize(h->ev_poll[ps & 1]));
             const int* sn = pinned + (ps & 1) * (1 + MAX_CHUNKS);
+            {   // alive rows now <= alive rows in that snapshot + rows admitted after it was taken
+                int after = 0;
+                for (auto& a : admits) if (a.first > ps) after += a.second;
+                bound = std::min(bound, sn[0] + after);
+                while (!admits.empty() && admits.front().first <= ps) admits.erase(admits.begin());
+            }
             for (size_t i = 0; i < live.size();) {
                 Chunk& ck = live[i];
                 if (ck.admit_seq <= ps && sn[1 + ck.tag] == 0) {
