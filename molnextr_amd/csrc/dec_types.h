@@ -5,7 +5,8 @@
 
 namespace mnx {
 
-constexpr int MAX_SLOTS = 1024;    // decode rows resident on the GPU at once (32 reference batches of 32)
+constexpr int MAX_SLOTS = 2048;    // sequence state slots resident on the GPU (64 reference batches of 32)
+constexpr int BEGIN_THREADS = 1024;
 constexpr int ROW_TILE = 32;       // rows per workgroup of the skinny linears; also the max reference batch
 constexpr int MAX_DEC_LAYERS = 8;
 constexpr int MAX_CHUNKS = 64;     // reference batches in flight (slots of one batch may be scattered)

@@ -419,37 +419,50 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
 
 // Opens a tick: PE rank of every slot (rank among the alive slots of its chunk, by row index) and the alive
 // counters the host polls. One workgroup; the kernel boundary is the all-rows barrier.
-__global__ __launch_bounds__(MAX_SLOTS) void dec_begin_kernel(DecState* st, int slots) {
+__global__ __launch_bounds__(BEGIN_THREADS) void dec_begin_kernel(DecState* st, int slots) {
     __shared__ unsigned int s_mask[MAX_CHUNKS];     // bit r = row r of the chunk is alive (rows per chunk <= 32)
-    __shared__ int s_wave[MAX_SLOTS / 64];
+    __shared__ int s_wave[BEGIN_THREADS / 64];
+    __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < MAX_CHUNKS) s_mask[tid] = 0u;
-    const int al = tid < slots ? st->alive[tid] : 0;
-    const int c = tid < slots ? (st->chunk[tid] & (MAX_CHUNKS - 1)) : 0;
-    const int rc = tid < slots ? (st->rowc[tid] & 31) : 0;
-    // compact list of alive slots, in slot order (ballot prefix per wave + wave offsets)
-    const unsigned long long bal = __ballot(al != 0);
-    if (lane == 0) s_wave[wave] = __popcll(bal);
+    if (tid == 0) s_base = 0;
     __syncthreads();
-    if (al) atomicOr(&s_mask[c], 1u << rc);
-    int base = 0, total = 0;
-    for (int w = 0; w < MAX_SLOTS / 64; ++w) {
-        const int cw = s_wave[w];
-        if (w < wave) base += cw;
-        total += cw;
+    // pass 1: per-chunk alive bitmaps + compact list of alive slots in slot order
+    for (int s0 = 0; s0 < slots; s0 += BEGIN_THREADS) {
+        const int s = s0 + tid;
+        const int al = s < slots ? st->alive[s] : 0;
+        const unsigned long long bal = __ballot(al != 0);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        if (al) atomicOr(&s_mask[st->chunk[s] & (MAX_CHUNKS - 1)], 1u << (st->rowc[s] & 31));
+        __syncthreads();
+        int base = s_base, total = 0;
+        for (int w = 0; w < BEGIN_THREADS / 64; ++w) {
+            const int cw = s_wave[w];
+            if (w < wave) base += cw;
+            total += cw;
+        }
+        if (al) st->active[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
     }
-    if (al) st->active[base + __popcll(bal & ((1ull << lane) - 1ull))] = tid;
-    __syncthreads();
-    if (al) st->rank[tid] = __popc(s_mask[c] & ((1u << rc) - 1u));
+    // pass 2: PE rank of every alive slot = alive chunk-mates with a smaller row index
+    for (int s = tid; s < slots; s += BEGIN_THREADS)
+        if (st->alive[s]) {
+            const int c = st->chunk[s] & (MAX_CHUNKS - 1), rc = st->rowc[s] & 31;
+            st->rank[s] = __popc(s_mask[c] & ((1u << rc) - 1u));
+        }
     if (tid < MAX_CHUNKS) st->chunk_alive[tid] = __popc(s_mask[tid]);
-    if (tid == 0) { st->n_active = total; st->tick = st->tick + 1; }
+    if (tid == 0) { st->n_active = s_base; st->tick = st->tick + 1; }
 }
 
-__global__ __launch_bounds__(MAX_SLOTS) void dec_reset_kernel(DecState* st) {
-    const int i = threadIdx.x;
-    if (i == 0) { st->tick = 0; st->n_active = 0; }
-    if (i < MAX_CHUNKS) st->chunk_alive[i] = 0;
-    if (i < MAX_SLOTS) { st->alive[i] = 0; st->t[i] = 0; st->len[i] = 0; st->chunk[i] = -1; st->rank[i] = 0; }
+__global__ __launch_bounds__(BEGIN_THREADS) void dec_reset_kernel(DecState* st) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { st->tick = 0; st->n_active = 0; }
+    if (tid < MAX_CHUNKS) st->chunk_alive[tid] = 0;
+    for (int i = tid; i < MAX_SLOTS; i += BEGIN_THREADS) {
+        st->alive[i] = 0; st->t[i] = 0; st->len[i] = 0; st->chunk[i] = -1; st->rank[i] = 0;
+    }
 }
 
 // Admit n rows of one reference batch into the given slots (any free slots).
@@ -472,12 +485,12 @@ static void lin(hipStream_t s, const LinArgs& a, int slots) {
 }
 
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s) {
-    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st, slots);
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots);
     return hipGetLastError();
 }
 
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s) {
-    hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st);
+    hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st);
     return hipGetLastError();
 }
 
@@ -494,7 +507,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
     // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
     const int D = 256, H = w.heads, T = b.T;
     const int slots = rows;
-    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(MAX_SLOTS), 0, s, b.st, slots_scan);
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& L = w.L[l];
         float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;

@@ -496,7 +496,7 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
             hipEventCreateWithFlags(&h->ev_feat_free[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_poll[i], hipEventDisableTiming) != hipSuccess)
             P.problems.push_back("event create failed");
-    if (hipHostMalloc((void**)&h->host_flag, 16384) != hipSuccess) P.problems.push_back("hipHostMalloc failed");
+    if (hipHostMalloc((void**)&h->host_flag, 32768) != hipSuccess) P.problems.push_back("hipHostMalloc failed");
 
     if (!P.problems.empty()) {
         g_create_error = "mnx_create: " + std::to_string(P.problems.size()) + " problem(s):";
@@ -801,7 +801,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         if (live.empty()) continue;       // (only possible before the first admission)
         // ---- a group of ticks, then a status snapshot
         // launch the tick graph sized for the alive-row bound (dense active list: idle row tiles are not launched)
-        static const int caps[] = {64, 128, 192, 256, 384, 512, 768, 1024};
+        static const int caps[] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048};
         int rows_cap = SL;
         for (int cp : caps) if (cp >= bound) { rows_cap = cp; break; }
         hipGraphExec_t exec = nullptr;
