@@ -106,7 +106,7 @@ def cpu_baseline(ck, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--mode", default="pipeline", choices=["pipeline", "batch"])
     ap.add_argument("--max-len", type=int, default=480)

@@ -48,15 +48,15 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // GELU for 16-bit outputs (encoder MLP): erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16/fp16
 // rounding of the stored result) — ~12 VALU ops instead of libm erff's ~40.
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float a = fabsf(z);
-    const float t = __frcp_rn(fmaf(0.3275911f, a, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-a * a);
-    return 0.5f * x * (1.0f + copysignf(e, z));
+    // x * Phi(x), Phi(x) = 1 - u (x >= 0) or u (x < 0), u = 0.5 * p(t) * exp(-x^2/2), t = 1 / (1 + 0.3275911 |x| / sqrt2)
+    const float a = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164190f, a, 1.0f));
+    float p = fmaf(t, 0.5307027145f, -0.7265760135f);       // A&S 7.1.26 coefficients, pre-multiplied by 0.5
+    p = fmaf(t, p, 0.7107068705f);
+    p = fmaf(t, p, -0.142248368f);
+    p = fmaf(t, p, 0.127414796f);
+    const float u = p * t * __builtin_amdgcn_exp2f(a * a * -0.72134752044f);   // exp(-a^2/2) = 2^(-a^2/2 * log2 e)
+    return x * (x >= 0.f ? 1.0f - u : u);
 }
 
 // bijective XCD-aware remap of a linear workgroup id (guide T1): consecutive ids land on the same XCD/L2.
