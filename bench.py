@@ -223,7 +223,7 @@ def main():
                                    f"decode to EOS (max_length {args.max_len}) + atom positions + bond head"
                                    + (", RCCL all-gather of result records" if world > 1 else ""),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world,
-                       "mode": ("continuous batching: <= 8 reference batches resident in the decoder"
+                       "mode": ("continuous batching: up to 64 reference batches (2048 sequences) resident in the decoder"
                                 if args.mode == "pipeline" else "one batch at a time"),
                        "decoded_len_mean": round(float(np.mean(stats["lens"])), 1),
                        "decoded_len_max": int(np.max(stats["lens"])),

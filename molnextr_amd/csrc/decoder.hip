@@ -556,33 +556,41 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
 // sequence (reference tokenization.py:464-515): for every atom token group followed by "x y <next>", the
 // position of <next>. One thread per sequence (a <= 480-step scan).
 // =============================================================================================
-__global__ void atom_scan_kernel(const int* __restrict__ lens, const int* __restrict__ tokens,
-                                 const TokenClasses* __restrict__ tc, const int* __restrict__ slots, int n_rows, int T,
-                                 int kmax, int* __restrict__ atom_idx, int* __restrict__ n_atoms) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+__global__ __launch_bounds__(64) void atom_scan_kernel(const int* __restrict__ lens, const int* __restrict__ tokens,
+                                                       const TokenClasses* __restrict__ tc, const int* __restrict__ slots,
+                                                       int n_rows, int T, int kmax, int* __restrict__ atom_idx,
+                                                       int* __restrict__ n_atoms) {
+    // one workgroup per sequence: the ids are staged in LDS by all lanes, then lane 0 runs the sequential scan
+    __shared__ int seq[512];
+    __shared__ unsigned char fl[256];
+    const int row = blockIdx.x;
     const int slot = slots ? slots[row] : row;
-    const int* seq = tokens + (size_t)slot * T;
-    const int n = lens[slot];
+    const int n = min(lens[slot], 512);
+    for (int i = threadIdx.x; i < n; i += 64) seq[i] = tokens[(size_t)slot * T + i];
+    for (int i = threadIdx.x; i < 256; i += 64) fl[i] = tc->flags[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int x0 = tc->x0, y0 = tc->y0, lb = tc->lbracket, rb = tc->rbracket;
+    const int iC = tc->id_C, il = tc->id_l, iB = tc->id_B, ir = tc->id_r;
     int i = 0, k = 0;
     while (i < n) {
         const int t = seq[i];
         if (t == 2 || t == 0) break;                                  // <eos> / <pad>
-        if (t >= tc->x0) { ++i; continue; }                           // coordinate bins
-        if (!(tc->flags[t] & 2)) { ++i; continue; }                   // not an atom token
+        if (t >= x0) { ++i; continue; }                               // coordinate bins
+        if (!(fl[t] & 2)) { ++i; continue; }                          // not an atom token
         int j;
-        if (t == tc->lbracket) {
+        if (t == lb) {
             j = i + 1;
-            while (j < n && seq[j] < tc->x0 && (tc->flags[seq[j]] & 1)) {
+            while (j < n && seq[j] < x0 && (fl[seq[j]] & 1)) {
                 ++j;
-                if (seq[j - 1] == tc->rbracket) break;
+                if (seq[j - 1] == rb) break;
             }
-        } else if (i + 1 < n && ((t == tc->id_C && seq[i + 1] == tc->id_l) || (t == tc->id_B && seq[i + 1] == tc->id_r))) {
+        } else if (i + 1 < n && ((t == iC && seq[i + 1] == il) || (t == iB && seq[i + 1] == ir))) {
             j = i + 2;
         } else {
             j = i + 1;
         }
-        if (j + 2 < n && seq[j] >= tc->x0 && seq[j] < tc->y0 && seq[j + 1] >= tc->y0) {
+        if (j + 2 < n && seq[j] >= x0 && seq[j] < y0 && seq[j + 1] >= y0) {
             if (k < kmax) atom_idx[(size_t)row * kmax + k] = j + 2;
             ++k;
             i = j + 2;
@@ -595,15 +603,15 @@ __global__ void atom_scan_kernel(const int* __restrict__ lens, const int* __rest
 
 hipError_t atoms_enqueue(const DecBuffers& b, const TokenClasses* tc_dev, const int* slots_dev, int n, int kmax,
                          int* atom_idx, int* n_atoms, hipStream_t s) {
-    hipLaunchKernelGGL(atom_scan_kernel, dim3((n + 63) / 64), dim3(64), 0, s, b.st->len, b.tokens, tc_dev, slots_dev, n,
-                       b.T, kmax, atom_idx, n_atoms);
+    hipLaunchKernelGGL(atom_scan_kernel, dim3(n), dim3(64), 0, s, b.st->len, b.tokens, tc_dev, slots_dev, n, b.T, kmax,
+                       atom_idx, n_atoms);
     return hipGetLastError();
 }
 
 hipError_t atoms_enqueue_raw(const TokenClasses* tc_dev, const int* tokens, const int* lens, int n, int T, int kmax,
                              int* atom_idx, int* n_atoms, hipStream_t s) {
-    hipLaunchKernelGGL(atom_scan_kernel, dim3((n + 63) / 64), dim3(64), 0, s, lens, tokens, tc_dev, (const int*)nullptr,
-                       n, T, kmax, atom_idx, n_atoms);
+    hipLaunchKernelGGL(atom_scan_kernel, dim3(n), dim3(64), 0, s, lens, tokens, tc_dev, (const int*)nullptr, n, T, kmax,
+                       atom_idx, n_atoms);
     return hipGetLastError();
 }
 

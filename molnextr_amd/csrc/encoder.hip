@@ -19,10 +19,12 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ x,
                                                           int S, int C, int G) {
+    // 32 patches per workgroup; 8 threads per patch, each owning CPT = C/8 consecutive channels (<= 16), so the
+    // LayerNorm reduction is 3 cross-lane steps and every patch row is written as one contiguous C*4-byte run.
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wt = sm;             // [48][C]
     float* pix = sm + 48 * C;   // [3][4][128]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int px0 = blockIdx.x * 32, py = blockIdx.y, b = blockIdx.z;
     for (int i = tid; i < 48 * C; i += 256) wt[i] = w_t[i];
     for (int i = tid; i < 3 * 4 * 128; i += 256) {
@@ -31,27 +33,45 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
         pix[i] = gx < S ? img[((size_t)(b * 3 + ci) * S + (py * 4 + ky)) * S + gx] : 0.f;
     }
     __syncthreads();
-    const bool c0 = lane < C, c1 = lane + 64 < C;
-    const float b0 = c0 ? bias[lane] : 0.f, b1 = c1 ? bias[lane + 64] : 0.f;
-    const float g0 = c0 ? gamma[lane] : 0.f, g1 = c1 ? gamma[lane + 64] : 0.f;
-    const float e0 = c0 ? beta[lane] : 0.f, e1 = c1 ? beta[lane + 64] : 0.f;
-    for (int p = wave * 8; p < wave * 8 + 8; ++p) {
-        const int px = px0 + p;
-        if (px >= G) break;
-        float a0 = b0, a1 = b1;
+    const int p = tid >> 3, part = tid & 7;
+    const int px = px0 + p;
+    const int cpt = C >> 3;                 // channels per thread: 4, 8, 12 or 16
+    const int c0 = part * cpt;
+    float acc[16];
 #pragma unroll
-        for (int i = 0; i < 48; ++i) {
-            const float v = pix[((i >> 2) << 7) + p * 4 + (i & 3)];  // (ci*4+ky)*128 + p*4 + kx
-            if (c0) a0 = fmaf(v, wt[i * C + lane], a0);
-            if (c1) a1 = fmaf(v, wt[i * C + lane + 64], a1);
-        }
-        const float mean = wave_sum((c0 ? a0 : 0.f) + (c1 ? a1 : 0.f)) / (float)C;
-        const float d0 = c0 ? a0 - mean : 0.f, d1 = c1 ? a1 - mean : 0.f;
-        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)C + 1e-5f);
-        float* o = x + ((size_t)(b * G + py) * G + px) * C;
-        if (c0) o[lane] = d0 * rstd * g0 + e0;
-        if (c1) o[lane + 64] = d1 * rstd * g1 + e1;
+    for (int j = 0; j < 16; ++j) acc[j] = j < cpt ? bias[c0 + j] : 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 48; ++i) {
+        const float v = pix[((i >> 2) << 7) + p * 4 + (i & 3)];  // (ci*4+ky)*128 + p*4 + kx
+        const float* wr = wt + i * C + c0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4)
+            if (j < cpt) {
+                const f32x4 w4 = *(const f32x4*)(wr + j);
+                acc[j] = fmaf(v, w4[0], acc[j]); acc[j + 1] = fmaf(v, w4[1], acc[j + 1]);
+                acc[j + 2] = fmaf(v, w4[2], acc[j + 2]); acc[j + 3] = fmaf(v, w4[3], acc[j + 3]);
+            }
     }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += j < cpt ? acc[j] : 0.f;
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    const float mean = s / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < cpt) { acc[j] -= mean; sq += acc[j] * acc[j]; }
+    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+    const float rstd = rsqrtf(sq / (float)C + 1e-5f);
+    if (px >= G) return;
+    float* o = x + ((size_t)(b * G + py) * G + px) * C + c0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4)
+        if (j < cpt) {
+            const f32x4 g4 = *(const f32x4*)(gamma + c0 + j), b4 = *(const f32x4*)(beta + c0 + j);
+            f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
+            *(f32x4*)(o + j) = v * rstd * g4 + b4;
+        }
 }
 
 hipError_t launch_patch_embed(const float* img, const float* w_t, const float* bias, const float* gamma,

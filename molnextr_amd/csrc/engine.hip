@@ -752,6 +752,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     FILE* tf = trace_path ? fopen(trace_path, "a") : nullptr;
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_begin = now_ms();
+    double host_wait_ms = 0.0;
     int next_enc = 0;                       // next chunk to hand to the encoder stream
     int fb_chunk[2] = {-1, -1};             // chunk whose features sit (or are being produced) in feature buffer i
     bool feat_used[2] = {false, false};
@@ -816,7 +817,9 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         // ---- retire chunks that the PREVIOUS snapshot shows finished (the GPU keeps ticking meanwhile)
         if (seq > 0) {
             const int ps = seq - 1;
+            const double tw0 = tf ? now_ms() : 0.0;
             HIPCHK(h, hipEventSynchronize(h->ev_poll[ps & 1]));
+            if (tf) host_wait_ms += now_ms() - tw0;
             const int* sn = pinned + (ps & 1) * (1 + MAX_CHUNKS);
             {   // alive rows now <= alive rows in that snapshot + rows admitted after it was taken
                 int after = 0;
@@ -849,7 +852,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         if (seq > 200000) { h->err = "mnx_predict: watchdog (decode did not terminate)"; return MNX_ERR_HIP; }
     }
     HIPCHK(h, hipStreamSynchronize(s));
-    if (tf) { fprintf(tf, "%.3f end\n", now_ms() - t_begin); fclose(tf); }
+    if (tf) { fprintf(tf, "%.3f end host_wait_ms %.3f\n", now_ms() - t_begin, host_wait_ms); fclose(tf); }
     return MNX_OK;
 }
 
