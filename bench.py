@@ -141,6 +141,7 @@ def main():
         return torch.cat([pool[(first_step + i) % n_distinct] for i in range(count)]).to(dev).contiguous()
 
     stats = {}
+    host_buf = {}
 
     def run(first_step, count):
         imgs = images_for(first_step, count)
@@ -167,7 +168,14 @@ def main():
         if rec is not None:
             if world > 1 or args.force_gather:   # result gather over xGMI: fixed-size records, one RCCL all-gather
                 rec = shard.gather_records(rec, force=args.force_gather)
-            rec = rec.cpu()
+            # results land in pinned host memory: every rank keeps its own shard, rank 0 the gathered whole
+            mine = rec if (rank == 0 or world == 1) else rec[rank * count * BATCH:(rank + 1) * count * BATCH]
+            key = tuple(mine.shape)
+            if key not in host_buf:
+                host_buf[key] = torch.empty(mine.shape, dtype=mine.dtype, pin_memory=True)
+            host_buf[key].copy_(mine, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            rec = host_buf[key]
         return rec
 
     def barrier():

@@ -321,6 +321,20 @@ def test_facade_reference_batch_size_semantics(eng, dev, synth_ckpt):
         assert all(0.0 < s <= 1.0 for s in p["chartok_coords"]["atom_scores"])
 
 
+def test_pipeline_facade_equals_per_batch_facade(eng, dev):
+    """predict_pipeline (mnx_predict) and encode + decode_batch must give identical per-image dicts, with the
+    reference's default batch_size=16 as the numbering unit."""
+    from molnextr_amd.model import decode_batch, predict_pipeline
+    imgs = W.synthetic_images(40, first_index=200).to(dev)
+    a = predict_pipeline(eng, imgs, ref_batch_size=16)
+    b = []
+    for i in range(0, 40, 32):
+        b += decode_batch(eng, eng.encode(imgs[i:i + 32].contiguous()), ref_batch_size=16)
+    assert len(a) == len(b) == 40
+    for x, y in zip(a, b):
+        assert x == y
+
+
 def test_public_api_predict_images_synthetic(dev):
     """molnextr('synthetic').predict_images: reference output dict keys; no RDKit here -> SMILES fields None."""
     from molnextr_amd.model import molnextr, BOND_TYPES
