@@ -237,6 +237,7 @@ __global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __res
     __shared__ __attribute__((aligned(16))) T Vt[HD * VT_STRIDE];
     __shared__ float tab[(2 * WS - 1) * (2 * WS - 1)];
     __shared__ int rowof[WN];
+    __shared__ __attribute__((aligned(16))) int kinfo[WN];   // per key: (ky*23 + kx) | region id << 16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nWw = W / WS, nWh = H / WS;
@@ -246,11 +247,15 @@ __global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __res
     const int wy = bid % nWh;
     const int b = bid / nWh;
 
+    const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
     for (int t = tid; t < WN; t += NTHR) {
-        int ys = wy * WS + t / WS, xs = wx * WS + t % WS;
+        const int ty = t / WS, tx = t % WS;
+        int ys = wy * WS + ty, xs = wx * WS + tx;
         int yo = ys + shift; if (yo >= H) yo -= H;
         int xo = xs + shift; if (xo >= W) xo -= W;
         rowof[t] = (b * H + yo) * W + xo;
+        const int reg = (last_y ? (ty < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (tx < WS - shift ? 1 : 2) : 0);
+        kinfo[t] = (ty * (2 * WS - 1) + tx) | (reg << 16);
     }
     for (int i = tid; i < 529; i += NTHR) tab[i] = table[i * heads + head];
     for (int i = tid; i < HD * (VT_STRIDE - WN); i += NTHR)
@@ -289,26 +294,26 @@ __global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __res
 
     // ---- scale + relative-position bias + shift mask, softmax over keys ----------------------
     const float scale = 0.17677669529663687f;  // 32^-0.5 (reference scales q before QK^T; same product)
-    const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
     float inv_sum[QT];
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
-        const int qi = (wave * QT + q) * 16 + fr;
-        const int qy = qi / WS, qx = qi % WS;
-        const int rq = (last_y ? (qy < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (qx < WS - shift ? 1 : 2) : 0);
+        const int qinfo = kinfo[(wave * QT + q) * 16 + fr];
+        // bias index = (qy-ky+11)*23 + (qx-kx+11) = (qy*23+qx + 11*24) - (ky*23+kx)
+        const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS);
+        const int rq = qinfo >> 16;
         float mx = -3.0e38f;
 #pragma unroll
-        for (int kt = 0; kt < 9; ++kt)
+        for (int kt = 0; kt < 9; ++kt) {
+            const int4 ki4 = *(const int4*)(kinfo + kt * 16 + fg * 4);
+            const int kis[4] = {ki4.x, ki4.y, ki4.z, ki4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ki = kt * 16 + fg * 4 + r;
-                const int ky = ki / WS, kx = ki % WS;
-                const int rk = (last_y ? (ky < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (kx < WS - shift ? 1 : 2) : 0);
-                float s = acc[q][kt][r] * scale + tab[(qy - ky + WS - 1) * (2 * WS - 1) + (qx - kx + WS - 1)];
-                if (rq != rk) s += -100.0f;
+                float s = acc[q][kt][r] * scale + tab[qa - (kis[r] & 0xffff)];
+                if ((kis[r] >> 16) != rq) s += -100.0f;
                 acc[q][kt][r] = s;
                 mx = fmaxf(mx, s);
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;

@@ -321,6 +321,25 @@ def test_facade_reference_batch_size_semantics(eng, dev, synth_ckpt):
         assert all(0.0 < s <= 1.0 for s in p["chartok_coords"]["atom_scores"])
 
 
+def test_confidence_outputs_vs_reference_golden(golden_dir, eng, dev):
+    """Decoder.decode(compute_confidence=True): atom / edge / overall scores against the reference's own output."""
+    from molnextr_amd.model import decode_batch
+    with open(os.path.join(golden_dir, "predict_e2e_conf.json")) as f:
+        gold = json.load(f)["preds"]
+    feats = W.hash_normal("conf_features", (3, 144, 1024), 0.5).to(dev)
+    preds = decode_batch(eng, feats, compute_confidence=True)
+    for p, g in zip(preds, gold):
+        c = p["chartok_coords"]
+        assert c["smiles"] == g["smiles"] and c["indices"] == g["indices"]
+        np.testing.assert_allclose(c["atom_scores"], g["atom_scores"], rtol=2e-4)
+        es = np.array(p["edge_scores"])
+        np.testing.assert_allclose(es.sum(axis=1), g["edge_score_row_sums"], rtol=1e-5)
+        np.testing.assert_allclose(np.log(es).sum(), g["edge_score_log_sum"], rtol=1e-4)
+        if g["edge_scores"] is not None:
+            np.testing.assert_allclose(es, np.array(g["edge_scores"]), atol=1e-5)
+        assert abs(p["overall_score"] - g["overall_score"]) <= 1e-6 + 1e-3 * abs(g["overall_score"])
+
+
 def test_pipeline_facade_equals_per_batch_facade(eng, dev):
     """predict_pipeline (mnx_predict) and encode + decode_batch must give identical per-image dicts, with the
     reference's default batch_size=16 as the numbering unit."""

@@ -18,6 +18,7 @@ Fixtures (all small):
   edges.npz            GraphPredictor + softmax + get_edge_prediction on hash hidden states
   tokenizer.json       get_output_mask truth table (229 ids) + sequence_to_smiles cases
   predict_e2e.json     Decoder.decode end-to-end on B=4: smiles / symbols / coords / indices / edges
+  predict_e2e_conf.json  same with compute_confidence=True on B=3: atom / edge / overall scores
 """
 import hashlib
 import json
@@ -208,6 +209,27 @@ def gen_e2e(dec, feats):
     print("predict_e2e: atoms", [len(o["symbols"]) for o in out])
 
 
+def gen_e2e_confidence(dec, feats):
+    """Decoder.decode with compute_confidence=True (reference components.py:456-469,485-491)."""
+    dec.compute_confidence = True
+    with torch.no_grad():
+        preds = dec.decode(feats)
+    dec.compute_confidence = False
+    out = []
+    for p in preds:
+        c = p["chartok_coords"]
+        es = np.array(p["edge_scores"], dtype=np.float64)
+        out.append({"smiles": c["smiles"], "symbols": c["symbols"], "indices": c["indices"],
+                    "atom_scores": c["atom_scores"], "overall_score": p["overall_score"],
+                    # full matrix for the first (small) sample only; row sums + log-product for the rest
+                    "edge_scores": p["edge_scores"] if len(out) == 0 else None,
+                    "edge_score_row_sums": es.sum(axis=1).tolist(),
+                    "edge_score_log_sum": float(np.log(es).sum())})
+    with open(os.path.join(GOLD, "predict_e2e_conf.json"), "w") as f:
+        json.dump({"features": "hash_normal('conf_features',(3,144,1024),0.5)", "preds": out}, f)
+    print("predict_e2e_conf: atoms", [len(o["symbols"]) for o in out])
+
+
 def main():
     if not have_reference():
         raise SystemExit("/root/reference is not mounted: fixtures can only be regenerated in the build container")
@@ -231,6 +253,7 @@ def main():
     decoded = [g["ids"][b, :g["lens"][b]].tolist() for b in range(g["ids"].shape[0])]
     gen_tokenizer(tok, decoded)
     gen_e2e(dec, W.hash_normal("e2e_features", (4, 144, 1024), 0.5))
+    gen_e2e_confidence(dec, W.hash_normal("conf_features", (3, 144, 1024), 0.5))
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}
     print("fixture bytes:", sizes, "total", sum(sizes.values()))
 
