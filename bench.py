@@ -106,11 +106,13 @@ def cpu_baseline(ck, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--mode", default="pipeline", choices=["pipeline", "batch"])
     ap.add_argument("--max-len", type=int, default=480)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "64")),
+                    help="images per encoder launch group (a multiple of 32; decode batches stay 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL record gather even with one rank")
     args = ap.parse_args()
@@ -131,14 +133,14 @@ def main():
 
     ck = W.synthetic_checkpoint(0)
     tok = get_tokenizer()["chartok_coords"]
-    eng = Engine(ck["encoder"], ck["decoder"], device=local, max_batch=BATCH, dtype=args.dtype)
+    eng = Engine(ck["encoder"], ck["decoder"], device=local, max_batch=max(BATCH, args.encode_batch), dtype=args.dtype)
     kmax = eng.max_atoms
     # step s, rank r owns images [(s*world + r)*32, +32): every step has its own images (8 distinct batches cycle)
     n_distinct = 8
-    pool = [W.synthetic_images(BATCH, first_index=(s * world + rank) * BATCH) for s in range(n_distinct)]
+    pool = [W.synthetic_images(BATCH, first_index=(s * world + rank) * BATCH).to(dev) for s in range(n_distinct)]
 
     def images_for(first_step, count):
-        return torch.cat([pool[(first_step + i) % n_distinct] for i in range(count)]).to(dev).contiguous()
+        return torch.cat([pool[(first_step + i) % n_distinct] for i in range(count)]).contiguous()
 
     stats = {}
     host_buf = {}
@@ -200,7 +202,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    batches = [imgs[i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(args.steps, 4))]
+    eb = max(BATCH, args.encode_batch)   # the encoder launch group of the timed region: replay the same launches
+    batches = [imgs[i * eb:(i + 1) * eb].contiguous() for i in range(min(args.steps * BATCH // eb, 4))]
 
     out = None
     if rank == 0:
@@ -212,15 +215,17 @@ def main():
         eng.profile(False)
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", f"r01_gemm_traffic_b{eb}.json")
         if os.path.exists(tpath):       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_traffic.py)
             with open(tpath) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
-            traffic_src = "profiles/r01_gemm_traffic.json (separate rocprofv3 --pmc passes over the same encoder launches)"
+            traffic_src = (f"profiles/r01_gemm_traffic_b{eb}.json (separate rocprofv3 --pmc passes over the same "
+                           "encoder launches)")
         roofline = {"kernel": "mnx::gemm_tn_glds_kernel (bf16 MFMA 16x16x32, all encoder Linear layers)",
                     "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes()),
+                    "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb)),
+                    "images_per_launch": eb,
                     "launches": int(launches), "avg_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
                     "flop_per_launch_avg": round(gemm_flop / max(launches, 1))}
         cpu = None if args.no_cpu_baseline else cpu_baseline(ck)

@@ -466,8 +466,9 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     db.edge_uv = (float*)P.dalloc((size_t)ROW_TILE * db.kmax * 2 * D * 4);
     db.edge_prob = (float*)P.dalloc((size_t)ROW_TILE * db.kmax * db.kmax * 8 * 4);
     h->out_trace = nullptr;   // allocated lazily on first traced decode (test aid)
-    h->feat_ring[0] = (float*)P.dalloc((size_t)ROW_TILE * S * CF * 4);
-    h->feat_ring[1] = (float*)P.dalloc((size_t)ROW_TILE * S * CF * 4);
+    const size_t ring_rows = std::max<size_t>(ROW_TILE, MB);   // one encode group (max_batch images) per buffer
+    h->feat_ring[0] = (float*)P.dalloc(ring_rows * S * CF * 4);
+    h->feat_ring[1] = (float*)P.dalloc(ring_rows * S * CF * 4);
     h->slot_lists = (int*)P.dalloc((size_t)MAX_CHUNKS * ROW_TILE * 4);
     h->tc_dev = (TokenClasses*)P.dalloc(sizeof(TokenClasses));
     {
@@ -757,24 +758,32 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     double host_wait_ms = 0.0;
     static const int target_rows = getenv("MNX_TARGET_ROWS") ? atoi(getenv("MNX_TARGET_ROWS")) : 0;
     int next_enc = 0;                       // next chunk to hand to the encoder stream
-    int fb_chunk[2] = {-1, -1};             // chunk whose features sit (or are being produced) in feature buffer i
+    // the encoder is batch-invariant, so it runs on GROUPS of reference batches (as many as max_batch holds):
+    // bigger GEMM grids, half the launches; each reference batch of the group is admitted on its own
+    const int grp = std::max(1, c.max_batch / ref_batch);
+    int fb_first[2] = {-1, -1}, fb_count[2] = {0, 0};   // chunks [first, first+count) live in feature buffer i
     bool feat_used[2] = {false, false};
     const int ticks_per_poll = 4;
     while (done < n_chunks) {
-        // ---- encoder prefetch: keep both feature buffers busy on the (low-priority) encoder stream
+        // ---- encoder prefetch: keep both feature buffers busy on the encoder stream
         for (int fb = 0; fb < 2; ++fb) {
-            if (fb_chunk[fb] >= 0 || next_enc >= n_chunks) continue;
-            const int first = next_enc * ref_batch, n = std::min(ref_batch, n_img - first);
+            if (fb_first[fb] >= 0 || next_enc >= n_chunks) continue;
+            const int cnt = std::min(grp, n_chunks - next_enc);
+            const int first = next_enc * ref_batch, n = std::min(cnt * ref_batch, n_img - first);
             if (feat_used[fb]) HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_feat_free[fb], 0));
             rc = mnx_encode(h, images + (size_t)first * img_elems, n, h->feat_ring[fb], h->enc_stream);
             if (rc != MNX_OK) return rc;
             HIPCHK(h, hipEventRecord(h->ev_enc_done[fb], h->enc_stream));
-            fb_chunk[fb] = next_enc++;
+            fb_first[fb] = next_enc;
+            fb_count[fb] = cnt;
+            next_enc += cnt;
         }
         // ---- admission (in image order): only once the chunk's features are READY, so the decode stream never
         //      waits for the encoder; project the memory and admit on the decode stream
         while (next < n_chunks && !free_tags.empty()) {
-            const int fb = fb_chunk[0] == next ? 0 : (fb_chunk[1] == next ? 1 : -1);
+            int fb = -1;
+            for (int i = 0; i < 2; ++i)
+                if (fb_first[i] >= 0 && next >= fb_first[i] && next < fb_first[i] + fb_count[i]) fb = i;
             if (fb < 0) break;
             const int first = next * ref_batch, n = std::min(ref_batch, n_img - first);
             // nothing to decode, or fewer alive rows than the target tick size while the encoder still has work:
@@ -789,11 +798,14 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             for (int i = 0; i < n; ++i) ck.slots.push_back(ck.tag * ROW_TILE + i);
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_enc_done[fb], 0));   // already complete: ordering only
             float* memkv = h->db.mem_kv + (size_t)ck.tag * ROW_TILE * S * c.dec_layers * 2 * D;
-            HIPCHK(h, launch_sgemm_tn(h->feat_ring[fb], h->dw.w_enc, h->dw.b_enc, h->db.memory, n * S, D, h->dw.enc_dim, s));
+            const float* feats = h->feat_ring[fb] + (size_t)(next - fb_first[fb]) * ref_batch * S * h->dw.enc_dim;
+            HIPCHK(h, launch_sgemm_tn(feats, h->dw.w_enc, h->dw.b_enc, h->db.memory, n * S, D, h->dw.enc_dim, s));
             HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, memkv, n * S, c.dec_layers * 2 * D, D, s));
-            HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
-            feat_used[fb] = true;
-            fb_chunk[fb] = -1;
+            if (next + 1 == fb_first[fb] + fb_count[fb]) {    // last reference batch of the group: buffer is free again
+                HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
+                feat_used[fb] = true;
+                fb_first[fb] = -1;
+            }
             int* sl_dev = h->slot_lists + (size_t)ck.tag * ROW_TILE;
             int* sl_pin = pin_slots + (size_t)ck.tag * ROW_TILE;     // pinned, private to this tag until it retires
             for (int i = 0; i < n; ++i) sl_pin[i] = ck.slots[i];

@@ -261,6 +261,32 @@ def test_predict_pipeline_equals_per_batch_path(eng, dev):
             assert np.array_equal(ed[first + b, :k, :k], e[b, :k, :k]), f"image {first + b}: bonds"
 
 
+def _same_predictions(a, b):
+    a = {k: v.cpu().numpy() for k, v in a.items()}
+    b = {k: v.cpu().numpy() for k, v in b.items()}
+    assert np.array_equal(a["lengths"], b["lengths"]) and np.array_equal(a["n_atoms"], b["n_atoms"])
+    for i, (n, k) in enumerate(zip(a["lengths"], a["n_atoms"])):
+        assert np.array_equal(a["tokens"][i, :n], b["tokens"][i, :n]), f"image {i}: tokens"
+        assert np.array_equal(a["atom_idx"][i, :k], b["atom_idx"][i, :k]), f"image {i}: atom positions"
+        assert np.array_equal(a["edges"][i, :k, :k], b["edges"][i, :k, :k]), f"image {i}: bonds"
+
+
+def test_grouped_encode_gives_identical_predictions(eng, dev, synth_ckpt):
+    """An engine with max_batch=64 encodes several reference batches per encoder call (bigger GEMMs); the encoder is
+    batch-invariant, so tokens / atoms / bonds must equal the max_batch=32 engine's bit for bit (ragged last group)."""
+    from molnextr_amd.engine import Engine
+    imgs = W.synthetic_images(88, first_index=200).to(dev)       # reference batches of 16: 5 full + one of 8
+    a = eng.predict(imgs, ref_batch=16)
+    big = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=64)
+    try:
+        b = big.predict(imgs, ref_batch=16)
+        c = big.predict(imgs[:40].contiguous(), ref_batch=32)   # group of one full + one ragged reference batch
+    finally:
+        big.close()
+    _same_predictions(a, b)
+    _same_predictions(c, eng.predict(imgs[:40].contiguous(), ref_batch=32))
+
+
 def test_device_atom_scan_vs_reference_golden_and_fuzz(golden_dir, eng, dev):
     """The on-device restatement of sequence_to_smiles' 'indices': reference golden cases + a fuzz against the host
     tokenizer (itself pinned by the same golden cases)."""

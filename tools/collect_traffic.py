@@ -2,7 +2,7 @@
 """HBM traffic of the MFMA GEMM kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — separate passes, as
 MI355X_MICROARCH.md prescribes). gfx950 correction: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
 streams (calibrated in this repo on a 512 MiB copy: FETCH_SIZE read exactly half, WRITE_SIZE exact), so reads are
-doubled. Units are KiB.   usage: collect_traffic.py fetch.db write.db out.json"""
+doubled. Units are KiB.   usage: collect_traffic.py fetch.db write.db out.json [batch]"""
 import json
 import sqlite3
 import sys
@@ -21,7 +21,7 @@ tot_f = sum(v[0] for k, v in f.items() if "gemm_tn" in k)
 n_f = sum(v[1] for k, v in f.items() if "gemm_tn" in k)
 tot_w = sum(v[0] for k, v in w.items() if "gemm_tn" in k)
 n_w = sum(v[1] for k, v in w.items() if "gemm_tn" in k)
-out = {"kernel": "gemm_tn*_kernel (all encoder GEMM launches of Swin-B @ B=32)", "launches_per_pass": n_f,
+out = {"kernel": f"gemm_tn*_kernel (all encoder GEMM launches of Swin-B @ B={sys.argv[4] if len(sys.argv) > 4 else 32})", "launches_per_pass": n_f,
        "read_bytes_per_launch": 2 * tot_f * 1024 / n_f, "write_bytes_per_launch": tot_w * 1024 / n_w,
        "hbm_bytes_per_launch": (2 * tot_f / n_f + tot_w / n_w) * 1024,
        "note": "FETCH_SIZE doubled (gfx950 undercount, calibrated); Infinity-Cache hits are counted as traffic"}
