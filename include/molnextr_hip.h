@@ -116,6 +116,23 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
                       int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, float* token_logp, float* hidden,
                       float* logits_trace, void* stream);
 
+/* Beam search over one reference batch — the `beam_size > 1` branch of TransformerDecoderAR.decode
+ * (MolNexTR/components.py:253-334 with decoding/beam_search.py). The reference's own branch cannot run;
+ * the strategy follows BeamSearch.advance/update_finished (beam_search.py:84-190: average log-prob over emitted
+ * tokens + 2, flat top-k over beam x vocab, -1e10 for finished beams, stop when the top beam finished and n_best
+ * hypotheses exist), the loop re-orders per step and tracks decoder outputs for the bond head (ours; documented in
+ * DESIGN.md).
+ *   features   device fp32 [B,144,1024], B <= 32 (one reference batch; PE row = row in the alive-images x beam batch)
+ *   beam       1..8,  n_best 1..beam
+ *   tokens     device int32 [B,n_best,max_len]  hypotheses by descending score; ids without SOS, EOS included
+ *   lengths    device int32 [B,n_best]          (0 where fewer than n_best hypotheses finished — cannot happen when
+ *                                                n_best <= beam, kept for robustness)
+ *   scores     device fp32 [B,n_best]           average log-prob as defined above
+ *   hidden     device fp32 [B,n_best,max_len,256] or NULL   decoder outputs along each hypothesis
+ * Synchronous with respect to its outputs. */
+int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t beam, int32_t n_best, int32_t max_len,
+                    int32_t* tokens, int32_t* lengths, float* scores, float* hidden, void* stream);
+
 /* Replaces the 'edges' branch of `Decoder.decode` (MolNexTR/components.py:470-491): GraphPredictor.forward
  * (:365-380), softmax over the 7 bond classes and get_edge_prediction (:383-400) incl. its float64 averaging.
  *   hidden   device fp32 [B,max_len,256] as written by mnx_decode_greedy

@@ -66,6 +66,30 @@ struct DecBuffers {
     int T, S, slots, mem_blocks, kmax;
 };
 
+// ---- beam search (a12): hypotheses of image i live in slots i*K .. i*K+K-1 ------------------------------
+constexpr int MAX_BEAM = 8;
+constexpr int BEAM_LP_STRIDE = 256;   // floats per row of the masked log-prob buffer (vocab <= 256)
+constexpr int BEAM_ANC_MAX = 512;     // ancestry entries per hypothesis held in LDS (max_len + 1 <= 512)
+
+struct BeamState {
+    int top_fin[ROW_TILE];             // the image's top beam has finished at some step
+    int n_hyps[ROW_TILE];              // finished hypotheses seen so far (all of them, not only the kept ones)
+    int pool_n[ROW_TILE];              // kept hypotheses (<= n_best)
+    int order[ROW_TILE][MAX_BEAM];     // rank -> storage index of the kept hypotheses (score descending, stable)
+    float pscore[ROW_TILE][MAX_BEAM];  // by storage index
+    int plen[ROW_TILE][MAX_BEAM];
+    float cum[ROW_TILE * MAX_BEAM];    // cumulative log-prob of every live hypothesis (by slot)
+};
+
+struct BeamBuffers {
+    BeamState* bs;
+    float* blp;      // [B*K, BEAM_LP_STRIDE] masked log-probs of the current step
+    int* anc;        // [B*K, anc_stride]: slot that holds step tau of the hypothesis (K/V, hidden at tau; id at tau-1)
+    int* ptok;       // [32, MAX_BEAM, T] ids of the kept hypotheses
+    float* phid;     // [32, MAX_BEAM, T, 256] decoder outputs of the kept hypotheses, or null
+    int B, K, n_best, anc_stride;
+};
+
 // token classes for the on-device atom-position scan (CharTokenizer.sequence_to_smiles 'indices')
 struct TokenClasses {
     unsigned char flags[256];      // bit0 is_symbol, bit1 is_atom
@@ -77,7 +101,10 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s);
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s);
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
-                            int trace_rows, hipStream_t s);
+                            int trace_rows, hipStream_t s, const BeamBuffers* beam = nullptr);
+hipError_t beam_enqueue_init(const DecBuffers& b, const BeamBuffers& bm, int max_len, hipStream_t s);
+hipError_t beam_enqueue_gather(const DecBuffers& b, const BeamBuffers& bm, int out_len, int* o_tokens, int* o_len,
+                               float* o_scores, float* o_hidden, hipStream_t s);
 hipError_t dec_enqueue_admit_rows(const DecBuffers& b, const int* chunk_ids_dev, int n, int max_len, int stop_on_eos,
                                   hipStream_t s);
 hipError_t gather_enqueue(const DecBuffers& b, const int* slots_dev, int n_rows, int out_len, int* o_tokens, int* o_len,

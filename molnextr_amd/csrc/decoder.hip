@@ -242,8 +242,11 @@ struct AttnArgs {
     const DecState* st;
     long long row_stride, head_stride;   // floats
     int kstride, fixed_keys, heads, cross;
+    const int* anc;      // ANC: [slots, anc_stride] slot that holds key tau of the hypothesis (beam search)
+    int anc_stride;
 };
 
+template <bool ANC>
 __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     // 4 waves per (slot, head): the keys are split over all 256 lanes for the scores (one 128-byte key row per
     // lane, all loads in flight at once) and over the 4 waves for P.V; partial results meet in LDS.
@@ -269,6 +272,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
         float s = -3.0e38f;
         if (key < nkeys) {
             const float* kp = Kb + (size_t)key * a.kstride;
+            if (ANC)   // the hypothesis' own past lives in the slots of its ancestors
+                kp = a.K + (long long)a.anc[(size_t)slot * a.anc_stride + key] * a.row_stride + hd * a.head_stride +
+                     (size_t)key * a.kstride;
             f32x4 kv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(kp + i * 4);
@@ -306,7 +312,11 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
 #pragma unroll 4
     for (int key = wave * 8 + kg; key < nk32; key += 32) {
         const int kk = key < nkeys ? key : nkeys - 1;
-        const f32x4 v = *(const f32x4*)(Vb + (size_t)kk * a.kstride + dq * 4);
+        const float* vp = Vb + (size_t)kk * a.kstride;
+        if (ANC)
+            vp = a.V + (long long)a.anc[(size_t)slot * a.anc_stride + kk] * a.row_stride + hd * a.head_stride +
+                 (size_t)kk * a.kstride;
+        const f32x4 v = *(const f32x4*)(vp + dq * 4);
         o += v * ps[key];       // ps[key] == 0 for key >= nkeys
     }
 #pragma unroll
@@ -341,9 +351,11 @@ struct HeadArgs {
     float* token_logp;     // [slots, T]
     float* hidden;         // [slots, T, 256]
     float* logits_trace;   // [T, trace_rows, V] or null (slots 0..trace_rows-1)
+    float* blp;            // BEAM: [slots, BEAM_LP_STRIDE] masked log-probs out (the pick kernel chooses)
     int V, VP, T, x0, y0, eos, trace_rows;
 };
 
+template <bool BEAM>
 __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __shared__ float hv[256];
     __shared__ float red[8];
@@ -392,6 +404,10 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     if (prev >= a.x0 && prev < a.y0) { if (tid < a.y0) lp = -10000.0f; }     // after an x-bin: only y-bins
     else if (prev >= a.y0)           { if (tid >= a.x0) lp = -10000.0f; }    // after a y-bin: no coordinate bins
     if (t == 0 && tid == a.eos) lp = -1e20f;                                  // min_length = 1
+    if (BEAM) {
+        if (valid) a.blp[(size_t)slot * BEAM_LP_STRIDE + tid] = lp;
+        return;
+    }
     if (!valid) lp = -3.0e38f;
     // argmax, lowest index wins ties (topk(1))
     float bv = lp;
@@ -501,13 +517,17 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
     return hipGetLastError();
 }
 
+__global__ void beam_begin_kernel(DecState* st, int B, int K);
+__global__ void beam_pick_kernel(DecState* st, BeamBuffers bm, const float* hidden, int* etok, int T, int V, int eos);
+
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
-                            int trace_rows, hipStream_t s) {
+                            int trace_rows, hipStream_t s, const BeamBuffers* beam) {
     // slots_scan: state slots the begin kernel scans; rows: capacity of the compact active list this tick is
     // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
     const int D = 256, H = w.heads, T = b.T;
     const int slots = rows;
-    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
+    if (beam) hipLaunchKernelGGL(beam_begin_kernel, dim3(1), dim3(256), 0, s, b.st, beam->B, beam->K);
+    else hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& L = w.L[l];
         float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;
@@ -521,7 +541,12 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         AttnArgs at = {};
         at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
         at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32; at.fixed_keys = 0;
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(256), 0, s, at);
+        if (beam) {
+            at.anc = beam->anc; at.anc_stride = beam->anc_stride;
+            hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(slots * H), dim3(256), 0, s, at);
+        } else {
+            hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(slots * H), dim3(256), 0, s, at);
+        }
         // self final_linear + residual
         a.in = b.ctx; a.W = L.wo; a.bias = L.bo; a.out = b.x; a.N = D; a.K = D;
         lin<0, 1>(s, a, slots);
@@ -532,7 +557,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         at.V = at.K + D;
         at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = 32; at.kstride = w.layers * 2 * D;
         at.fixed_keys = b.S; at.cross = 1;
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(slots * H), dim3(256), 0, s, at);
+        hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(slots * H), dim3(256), 0, s, at);
         // context final_linear + residual
         a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = b.x;
         lin<0, 1>(s, a, slots);
@@ -547,7 +572,13 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
     h.eos = 2; h.trace_rows = trace_rows;
-    hipLaunchKernelGGL(dec_head_kernel, dim3(slots), dim3(256), 0, s, h);
+    if (beam) {
+        h.blp = beam->blp;
+        hipLaunchKernelGGL(dec_head_kernel<true>, dim3(slots), dim3(256), 0, s, h);
+        hipLaunchKernelGGL(beam_pick_kernel, dim3(beam->B), dim3(256), 0, s, b.st, *beam, b.hidden, b.tokens, T, w.vocab, 2);
+    } else {
+        hipLaunchKernelGGL(dec_head_kernel<false>, dim3(slots), dim3(256), 0, s, h);
+    }
     return hipGetLastError();
 }
 
@@ -761,6 +792,196 @@ __global__ void dec_admit_rows_kernel(DecState* st, const int* chunk_ids, int n,
 hipError_t dec_enqueue_admit_rows(const DecBuffers& b, const int* chunk_ids_dev, int n, int max_len, int stop_on_eos,
                                   hipStream_t s) {
     hipLaunchKernelGGL(dec_admit_rows_kernel, dim3(1), dim3(64), 0, s, b.st, chunk_ids_dev, n, max_len, stop_on_eos, 1);
+    return hipGetLastError();
+}
+
+}  // namespace mnx
+
+namespace mnx {
+
+// =============================================================================================
+// Beam search. The strategy follows the reference's BeamSearch.advance / update_finished
+// (decoding/beam_search.py:84-190; pinned through oracle/beam.py's BeamStrategy): scores are cumulative log-probs
+// divided by (emitted tokens + 2) — the reference counts <sos> and the new token —, a flat top-K over K x V per
+// image (ties: lowest flat index), finished hypotheses keep their row with a cumulative log-prob of -1e10, an image
+// leaves the batch when its top beam has finished at some step and >= n_best hypotheses are stored; the n_best
+// kept are the best by score (stable). The decode loop around it is ours (the reference's cannot run):
+// back-pointers are followed through an ancestry table instead of re-ordering the K/V caches: entry tau of a
+// hypothesis names the slot whose cache row tau / hidden row tau it inherits, and whose id row tau-1 it emitted.
+// The positional-encoding row is the row in the current (alive images x K) batch, as for greedy.
+// =============================================================================================
+__global__ void beam_init_kernel(DecState* st, BeamBuffers bm, int max_len, int sos) {
+    const int tid = threadIdx.x, n = bm.B * bm.K;
+    if (tid < n) {
+        st->alive[tid] = 1; st->t[tid] = 0; st->prev_tok[tid] = sos; st->len[tid] = 0;
+        st->chunk[tid] = 0; st->rowc[tid] = tid; st->rank[tid] = tid; st->mem_blk[tid] = tid / bm.K;
+        st->max_len[tid] = max_len; st->stop_on_eos[tid] = 1;
+        bm.bs->cum[tid] = (tid % bm.K == 0) ? 0.0f : -__builtin_inff();     // beam_search.py:43-45
+        bm.anc[(size_t)tid * bm.anc_stride] = tid;
+    }
+    if (tid < ROW_TILE) { bm.bs->top_fin[tid] = 0; bm.bs->n_hyps[tid] = 0; bm.bs->pool_n[tid] = 0; }
+    if (tid == 0) st->n_active = n;
+}
+
+// rows of the step: alive images in index order x K; PE row = position in that batch
+__global__ void beam_begin_kernel(DecState* st, int B, int K) {
+    __shared__ int s_alive[ROW_TILE];
+    const int tid = threadIdx.x;
+    if (tid < ROW_TILE) s_alive[tid] = tid < B ? st->alive[tid * K] : 0;
+    __syncthreads();
+    int total = 0;
+    for (int i = 0; i < B; ++i) total += s_alive[i];
+    if (tid < B * K) {
+        const int img = tid / K, j = tid % K;
+        if (s_alive[img]) {
+            int r = 0;
+            for (int i = 0; i < img; ++i) r += s_alive[i];
+            st->rank[tid] = r * K + j;
+            st->active[r * K + j] = tid;
+        }
+    }
+    if (tid == 0) { st->n_active = total * K; st->chunk_alive[0] = total * K; st->tick = st->tick + 1; }
+}
+
+__global__ __launch_bounds__(256) void beam_pick_kernel(DecState* st, BeamBuffers bm, const float* hidden, int* etok,
+                                                        int T, int V, int eos) {
+    __shared__ int lanc[MAX_BEAM][BEAM_ANC_MAX];
+    __shared__ float r_val[4];
+    __shared__ int r_idx[4];
+    __shared__ float sel_score[MAX_BEAM];
+    __shared__ int sel_idx[MAX_BEAM];
+    __shared__ int task_src[MAX_BEAM], task_dst[MAX_BEAM];
+    __shared__ int n_tasks;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = bm.K, s0 = img * K;
+    if (!st->alive[s0]) return;
+    const int t = st->t[s0];                       // every hypothesis of the image is at the same step
+    const int max_len = st->max_len[s0];
+    const float len_f = (float)(t + 2);            // beam_search.py:99 `step + 1` with step = len(alive_seq)
+    const float NEG_INF = -__builtin_inff();
+    constexpr int PER = MAX_BEAM * BEAM_LP_STRIDE / 256;
+    float val[PER];
+    int idx[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int flat = tid + 256 * i;
+        val[i] = NEG_INF; idx[i] = 0x7fffffff;
+        if (flat < K * V) {
+            const int j = flat / V, v = flat - j * V;
+            val[i] = (bm.blp[(size_t)(s0 + j) * BEAM_LP_STRIDE + v] + bm.bs->cum[s0 + j]) / len_f;   // :97-100
+            idx[i] = flat;
+        }
+    }
+    for (int r = 0; r < K; ++r) {                  // top-K by K arg-max rounds (:69-82), ties -> lowest flat index
+        float bv = NEG_INF;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (val[i] > bv || (val[i] == bv && idx[i] < bi)) { bv = val[i]; bi = idx[i]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { r_val[wave] = bv; r_idx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (r_val[w] > bv || (r_val[w] == bv && r_idx[w] < bi)) { bv = r_val[w]; bi = r_idx[w]; }
+            sel_score[r] = bv; sel_idx[r] = bi;
+        }
+        __syncthreads();
+        const int won = sel_idx[r];
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (idx[i] == won) { val[i] = NEG_INF; idx[i] = 0x7fffffff; }
+    }
+    // ancestry of the K parents -> LDS, then every new hypothesis inherits its parent's
+    const int na = t + 1;
+    for (int e = tid; e < K * na; e += 256) {
+        const int j = e / na, tau = e - j * na;
+        lanc[j][tau] = bm.anc[(size_t)(s0 + j) * bm.anc_stride + tau];
+    }
+    __syncthreads();
+    for (int e = tid; e < K * na; e += 256) {
+        const int i = e / na, tau = e - i * na;
+        bm.anc[(size_t)(s0 + i) * bm.anc_stride + tau] = lanc[sel_idx[i] / V][tau];
+    }
+    if (tid < K) {
+        const int slot = s0 + tid, tok = sel_idx[tid] % V;
+        const bool fin = tok == eos || t + 1 >= max_len;           // decode_strategy.py:54-56
+        bm.anc[(size_t)slot * bm.anc_stride + t + 1] = slot;
+        etok[(size_t)slot * T + t] = tok;
+        st->prev_tok[slot] = tok; st->t[slot] = t + 1; st->len[slot] = t + 1;
+        bm.bs->cum[slot] = fin ? -1e10f : sel_score[tid] * len_f;  // :105, :134
+    }
+    if (tid == 0) {                                                // update_finished (:131-165)
+        BeamState* bs = bm.bs;
+        int top = bs->top_fin[img], nh = bs->n_hyps[img], pn = bs->pool_n[img], nt = 0;
+        for (int i = 0; i < K; ++i) {
+            const int tok = sel_idx[i] % V;
+            if (!(tok == eos || t + 1 >= max_len)) continue;
+            if (i == 0) top = 1;
+            ++nh;
+            const float sc = sel_score[i];
+            int pos = 0;
+            while (pos < pn && bs->pscore[img][bs->order[img][pos]] >= sc) ++pos;    // stable: after equal scores
+            if (pos >= bm.n_best) continue;
+            int storage;
+            if (pn == bm.n_best) storage = bs->order[img][pn - 1];                   // the worst kept one drops out
+            else storage = pn++;
+            for (int q = (pn < bm.n_best ? pn : bm.n_best) - 1; q > pos; --q) bs->order[img][q] = bs->order[img][q - 1];
+            bs->order[img][pos] = storage;
+            bs->pscore[img][storage] = sc;
+            bs->plen[img][storage] = t + 1;
+            task_src[nt] = i; task_dst[nt] = storage; ++nt;
+        }
+        bs->top_fin[img] = top; bs->n_hyps[img] = nh; bs->pool_n[img] = pn;
+        n_tasks = nt;
+        if (top && nh >= bm.n_best)                                                   // :152-153: the image is done
+            for (int j = 0; j < K; ++j) st->alive[s0 + j] = 0;
+    }
+    __syncthreads();
+    for (int q = 0; q < n_tasks; ++q) {            // materialise the kept hypotheses (ids + decoder outputs)
+        const int i = task_src[q], parent = sel_idx[i] / V, tok = sel_idx[i] % V;
+        const size_t dst = ((size_t)img * MAX_BEAM + task_dst[q]) * T;
+        for (int tau = tid; tau <= t; tau += 256)
+            bm.ptok[dst + tau] = tau == t ? tok : etok[(size_t)lanc[parent][tau + 1] * T + tau];
+        if (bm.phid)
+            for (int e = tid; e < (t + 1) * 64; e += 256) {
+                const int tau = e >> 6, c = e & 63;
+                ((f32x4*)bm.phid)[(dst + tau) * 64 + c] =
+                    ((const f32x4*)hidden)[((size_t)lanc[parent][tau] * T + tau) * 64 + c];
+            }
+        __syncthreads();
+    }
+}
+
+__global__ void beam_gather_kernel(BeamBuffers bm, int T, int out_len, int* __restrict__ o_tokens,
+                                   int* __restrict__ o_len, float* __restrict__ o_scores, float* __restrict__ o_hidden) {
+    const int r = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const size_t row = (size_t)img * bm.n_best + r;
+    const bool have = r < bm.bs->pool_n[img];
+    const int st = have ? bm.bs->order[img][r] : 0;
+    const int n = have ? min(bm.bs->plen[img][st], out_len) : 0;
+    if (tid == 0) { o_len[row] = n; o_scores[row] = have ? bm.bs->pscore[img][st] : -__builtin_inff(); }
+    const size_t src = ((size_t)img * MAX_BEAM + st) * T;
+    for (int i = tid; i < out_len; i += blockDim.x) o_tokens[row * out_len + i] = i < n ? bm.ptok[src + i] : 0;
+    if (o_hidden && bm.phid)
+        for (int i = tid; i < n * 64; i += blockDim.x)
+            ((f32x4*)o_hidden)[row * out_len * 64 + i] = ((const f32x4*)bm.phid)[src * 64 + i];
+}
+
+hipError_t beam_enqueue_init(const DecBuffers& b, const BeamBuffers& bm, int max_len, hipStream_t s) {
+    hipLaunchKernelGGL(beam_init_kernel, dim3(1), dim3(256), 0, s, b.st, bm, max_len, 1);
+    return hipGetLastError();
+}
+
+hipError_t beam_enqueue_gather(const DecBuffers& b, const BeamBuffers& bm, int out_len, int* o_tokens, int* o_len,
+                               float* o_scores, float* o_hidden, hipStream_t s) {
+    hipLaunchKernelGGL(beam_gather_kernel, dim3(bm.n_best, bm.B), dim3(256), 0, s, bm, b.T, out_len, o_tokens, o_len,
+                       o_scores, o_hidden);
     return hipGetLastError();
 }
 

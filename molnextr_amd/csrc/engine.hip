@@ -59,6 +59,7 @@ struct mnx_engine {
     DecWeights dw{};
     DecBuffers db{};
     float* out_trace = nullptr;
+    BeamBuffers beam{};        // allocated lazily on the first mnx_decode_beam
     int* host_flag = nullptr;  // pinned: [2][1 + MAX_CHUNKS] poll snapshots + slot lists
     std::map<GraphKey, hipGraphExec_t> graphs;
     // continuous-batching pipeline (mnx_predict)
@@ -668,6 +669,83 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
     }
     HIPCHK(h, gather_enqueue(h->db, nullptr, B, max_len, tokens, lengths, token_logp, hidden, s));
     if (logits_trace) HIPCHK(h, hipMemcpyAsync(logits_trace, trace, (size_t)max_len * B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return MNX_OK;
+}
+
+int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t beam, int32_t n_best, int32_t max_len,
+                    int32_t* tokens, int32_t* lengths, float* scores, float* hidden, void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!features || !tokens || !lengths || !scores || B < 1) {
+        h->err = "mnx_decode_beam: null/empty argument";
+        return MNX_ERR_INVALID_ARG;
+    }
+    const mnx_config& c = h->cfg;
+    if (B > ROW_TILE || beam < 1 || beam > MAX_BEAM || n_best < 1 || n_best > beam || max_len < 1 ||
+        max_len > c.max_len || c.max_len + 1 > BEAM_ANC_MAX || c.vocab > BEAM_LP_STRIDE) {
+        h->err = "mnx_decode_beam: B <= 32, 1 <= n_best <= beam <= 8, max_len <= cfg.max_len (<= 511) required";
+        return MNX_ERR_CAPACITY;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!s) {
+        if (!h->own_stream) HIPCHK(h, hipStreamCreate(&h->own_stream));
+        s = h->own_stream;
+    }
+    const int S = h->db.S, D = c.dec_dim, T = h->db.T;
+    BeamBuffers& bm = h->beam;
+    auto lazy = [&](void** p, size_t bytes) -> hipError_t {
+        if (*p) return hipSuccess;
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) h->allocs.push_back(*p);
+        return e;
+    };
+    HIPCHK(h, lazy((void**)&bm.bs, sizeof(BeamState)));
+    HIPCHK(h, lazy((void**)&bm.blp, (size_t)ROW_TILE * MAX_BEAM * BEAM_LP_STRIDE * 4));
+    HIPCHK(h, lazy((void**)&bm.anc, (size_t)ROW_TILE * MAX_BEAM * (T + 1) * 4));
+    HIPCHK(h, lazy((void**)&bm.ptok, (size_t)ROW_TILE * MAX_BEAM * T * 4));
+    if (hidden) HIPCHK(h, lazy((void**)&bm.phid, (size_t)ROW_TILE * MAX_BEAM * T * D * 4));
+    bm.B = B; bm.K = beam; bm.n_best = n_best; bm.anc_stride = T + 1;
+    BeamBuffers run = bm;
+    if (!hidden) run.phid = nullptr;
+    HIPCHK(h, launch_sgemm_tn(features, h->dw.w_enc, h->dw.b_enc, h->db.memory, B * S, D, h->dw.enc_dim, s));
+    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s));
+    HIPCHK(h, dec_enqueue_reset(h->db, s));
+    HIPCHK(h, beam_enqueue_init(h->db, run, max_len, s));
+    const int rows = (B * beam + ROW_TILE - 1) / ROW_TILE * ROW_TILE;
+    // one step = begin + 6 layers + head + pick, captured once per call (its arguments depend on B / beam / n_best)
+    hipGraph_t g = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (h->use_graph) {
+        HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        hipError_t e = dec_enqueue_tick(h->dw, h->db, rows, rows, nullptr, 0, s, &run);
+        hipError_t e2 = hipStreamEndCapture(s, &g);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            h->err = std::string("beam step capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+            return MNX_ERR_HIP;
+        }
+        HIPCHK(h, hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+        hipGraphDestroy(g);
+    }
+    int rc = MNX_OK;
+    const int poll = 8;
+    for (int t = 0; t < max_len && rc == MNX_OK;) {
+        const int n = std::min(poll, max_len - t);
+        for (int i = 0; i < n; ++i) {
+            hipError_t e = exec ? hipGraphLaunch(exec, s) : dec_enqueue_tick(h->dw, h->db, rows, rows, nullptr, 0, s, &run);
+            if (e != hipSuccess) { h->err = std::string("beam step: ") + hipGetErrorString(e); rc = MNX_ERR_HIP; break; }
+        }
+        if (rc != MNX_OK) break;
+        t += n;
+        hipError_t e = dec_enqueue_status(h->db, rows, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->host_flag, &h->db.st->n_active, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { h->err = std::string("beam poll: ") + hipGetErrorString(e); rc = MNX_ERR_HIP; break; }
+        if (*h->host_flag == 0) break;
+    }
+    if (exec) hipGraphExecDestroy(exec);
+    if (rc != MNX_OK) return rc;
+    HIPCHK(h, beam_enqueue_gather(h->db, run, max_len, tokens, lengths, scores, hidden, s));
     HIPCHK(h, hipStreamSynchronize(s));
     return MNX_OK;
 }

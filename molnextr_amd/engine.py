@@ -21,7 +21,7 @@ _lib = None
 ABI_VERSION = 1
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
-           "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan")
+           "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam")
 
 
 class MnxConfig(C.Structure):
@@ -83,6 +83,8 @@ def load_library():
     lib.mnx_set_token_classes.argtypes = [vp, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     lib.mnx_atom_scan.restype = C.c_int
     lib.mnx_atom_scan.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.mnx_decode_beam.restype = C.c_int
+    lib.mnx_decode_beam.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.mnx_predict.restype = C.c_int
     lib.mnx_predict.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
     if lib.mnx_abi_version() != ABI_VERSION:
@@ -216,6 +218,25 @@ class Engine:
                                         _stream())
         self._check(rc, "mnx_decode_greedy")
         return {"tokens": tokens, "lengths": lengths, "token_logp": logp, "hidden": hidden, "logits": trace}
+
+    # -- TransformerDecoderAR.decode, beam_size > 1 --------------------------------------------------
+    def decode_beam(self, features: torch.Tensor, beam: int = 5, n_best: int = 1, max_len: Optional[int] = None,
+                    want_hidden: bool = True) -> dict:
+        """Beam search over one reference batch (<= 32 images). Returns tokens [B,n_best,max_len], lengths
+        [B,n_best], scores [B,n_best] (average log-prob, hypotheses by descending score) and hidden
+        [B,n_best,max_len,256]."""
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        B = features.shape[0]
+        max_len = self.max_len if max_len is None else max_len
+        dev = features.device
+        tokens = torch.zeros(B, n_best, max_len, dtype=torch.int32, device=dev)
+        lengths = torch.zeros(B, n_best, dtype=torch.int32, device=dev)
+        scores = torch.zeros(B, n_best, dtype=torch.float32, device=dev)
+        hidden = torch.zeros(B, n_best, max_len, self.dec.d_model, dtype=torch.float32, device=dev) if want_hidden else None
+        rc = self.lib.mnx_decode_beam(self.h, _ptr(features), B, beam, n_best, max_len, _ptr(tokens), _ptr(lengths),
+                                      _ptr(scores), _ptr(hidden), _stream())
+        self._check(rc, "mnx_decode_beam")
+        return {"tokens": tokens, "lengths": lengths, "scores": scores, "hidden": hidden}
 
     # -- GraphPredictor + get_edge_prediction ----------------------------------------------------
     def edges(self, hidden: torch.Tensor, atom_idx: torch.Tensor, n_atoms: torch.Tensor, want_scores: bool = False):

@@ -26,7 +26,8 @@ ROWS = Engine.ROWS_PER_DECODE
 
 
 def decode_batch(engine: Engine, features: torch.Tensor, tokenizer=None, ref_batch_size: Optional[int] = None,
-                 compute_confidence: bool = False, max_len: Optional[int] = None) -> List[dict]:
+                 compute_confidence: bool = False, max_len: Optional[int] = None, beam_size: int = 1,
+                 n_best: int = 1) -> List[dict]:
     """Decoder.decode for formats ['chartok_coords', 'edges'] (reference components.py:443-492).
 
     features [B,144,1024] on the GPU. `ref_batch_size`: rows are numbered as if the reference had decoded them in
@@ -34,6 +35,11 @@ def decode_batch(engine: Engine, features: torch.Tensor, tokenizer=None, ref_bat
     rows are compacted away, so results depend on the batch composition); None = one batch of B (B <= 32) or
     batches of 32. Returns one dict per image: {'chartok_coords': {smiles, symbols, coords, indices[, atom_scores]},
     'edges': [[...]] [, 'edge_scores', 'overall_score']}.
+
+    beam_size > 1 (reference signature components.py:443; its own beam branch cannot run): the
+    best hypothesis of each image is detokenised, as the reference does with `pred[0]` (components.py:453-455), and
+    the bond head runs on the decoder outputs along that hypothesis; `beam_scores` lists the n_best average
+    log-probs. Token confidences are not tracked by beam search (nor by the reference's BeamSearch).
     """
     tok = (tokenizer or get_tokenizer())["chartok_coords"]
     B = features.shape[0]
@@ -41,12 +47,23 @@ def decode_batch(engine: Engine, features: torch.Tensor, tokenizer=None, ref_bat
     if rbs > ROWS:
         raise ValueError(f"reference batches larger than {ROWS} rows are not supported by one engine call")
     group = (ROWS // rbs) * rbs          # rows per engine call: whole reference batches only
+    if beam_size > 1:
+        if compute_confidence:
+            raise NotImplementedError("beam search does not track token scores (neither does the reference's)")
+        group = rbs                      # one reference batch per beam call
     preds: List[dict] = []
     for g0 in range(0, B, group):
         feats = features[g0:g0 + group].contiguous()
         n = feats.shape[0]
-        chunk = torch.arange(n, dtype=torch.int32) // rbs
-        out = engine.decode_greedy(feats, chunk_id=chunk, max_len=max_len, want_logp=True)
+        beam_scores = None
+        if beam_size > 1:
+            bo = engine.decode_beam(feats, beam=beam_size, n_best=n_best, max_len=max_len)
+            out = {"lengths": bo["lengths"][:, 0].contiguous(), "tokens": bo["tokens"][:, 0].contiguous(),
+                   "hidden": bo["hidden"][:, 0].contiguous()}
+            beam_scores = bo["scores"].cpu().numpy()
+        else:
+            chunk = torch.arange(n, dtype=torch.int32) // rbs
+            out = engine.decode_greedy(feats, chunk_id=chunk, max_len=max_len, want_logp=True)
         lens = out["lengths"].cpu().numpy()
         toks = out["tokens"].cpu().numpy()
         logp = out["token_logp"].cpu().numpy() if compute_confidence else None
@@ -65,6 +82,8 @@ def decode_batch(engine: Engine, features: torch.Tensor, tokenizer=None, ref_bat
         for b, r in enumerate(rows):
             k = int(n_atoms[b])
             pred = {"chartok_coords": r, "edges": edges[b, :k, :k].astype(int).tolist()}
+            if beam_scores is not None:
+                pred["beam_scores"] = beam_scores[b].tolist()
             if compute_confidence:   # reference components.py:456-469, 485-491
                 ts = np.exp(logp[b, :lens[b]].astype(np.float64))
                 idx = np.array(r["indices"]) - 3

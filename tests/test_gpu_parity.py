@@ -171,6 +171,71 @@ def test_decode_batch32_natural_lengths_vs_oracle(eng, dev, synth_ckpt):
     assert len(set(lens)) > 8, "workload should contain many different lengths"
 
 
+def test_beam1_equals_greedy(eng, dev):
+    """beam_size=1, n_best=1 must reproduce greedy search (natural lengths, compaction of finished images)."""
+    feats = W.hash_normal("decoder_features", (6, 144, 1024), 0.5).to(dev)
+    g = eng.decode_greedy(feats)
+    b = eng.decode_beam(feats, beam=1, n_best=1)
+    assert b["lengths"][:, 0].cpu().tolist() == g["lengths"].cpu().tolist()
+    for i, n in enumerate(g["lengths"].cpu().tolist()):
+        assert torch.equal(b["tokens"][i, 0, :n], g["tokens"][i, :n]), f"row {i}"
+        assert (b["hidden"][i, 0, :n] - g["hidden"][i, :n]).abs().max().item() < 1e-5
+        lp = g["token_logp"][i, :n].double().sum().item() / (n + 1)      # reference normalisation: tokens + <sos>
+        assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
+
+
+@pytest.mark.parametrize("B,beam,n_best,max_len", [(4, 3, 2, 160), (3, 5, 5, 96), (2, 8, 1, 64), (5, 2, 2, 480)])
+def test_beam_search_vs_oracle(eng, dev, synth_ckpt, B, beam, n_best, max_len):
+    """Beam search through the C ABI against oracle/beam.py (whose strategy is pinned on the reference's BeamSearch
+    class): hypotheses, their order, scores and the decoder outputs along each hypothesis."""
+    from oracle.beam import beam_decode
+    feats = W.hash_normal(f"beam_features_{B}_{beam}", (B, 144, 1024), 0.5)
+    ref = beam_decode(feats, synth_ckpt["decoder"], beam=beam, n_best=n_best, max_len=max_len)
+    out = eng.decode_beam(feats.to(dev), beam=beam, n_best=n_best, max_len=max_len)
+    lens = out["lengths"].cpu().numpy()
+    toks = out["tokens"].cpu().numpy()
+    sc = out["scores"].cpu().numpy()
+    for i in range(B):
+        assert len(ref.tokens[i]) == n_best
+        for r in range(n_best):
+            assert toks[i, r, :lens[i, r]].tolist() == ref.tokens[i][r], f"image {i} rank {r}"
+            assert abs(sc[i, r] - ref.scores[i][r]) < 1e-4 * max(1.0, abs(ref.scores[i][r]))
+            n = lens[i, r]
+            assert (out["hidden"][i, r, :n].cpu() - ref.hidden[i][r]).abs().max().item() < 1e-3
+    assert all(sc[i, r] >= sc[i, r + 1] for i in range(B) for r in range(n_best - 1))
+    # (no 'beam >= greedy' property: an image leaves the search when its TOP beam finishes, so a short hypothesis
+    #  can end the search below the score greedy reaches later — observed on these inputs)
+
+
+def test_beam_capacity_errors(eng, dev):
+    from molnextr_amd.engine import MnxError
+    feats = W.hash_normal("beam_err", (2, 144, 1024), 0.5).to(dev)
+    with pytest.raises(MnxError):
+        eng.decode_beam(feats, beam=9, n_best=1, max_len=16)
+    with pytest.raises(MnxError):
+        eng.decode_beam(feats, beam=2, n_best=3, max_len=16)
+
+
+def test_facade_beam_matches_engine_beam_and_bond_head(eng, dev, synth_ckpt):
+    """decode_batch(beam_size=3): best hypothesis detokenised, bond head on ITS decoder outputs (checked against the
+    oracle's beam + bond head)."""
+    from molnextr_amd.model import decode_batch
+    from oracle.beam import beam_decode
+    from oracle.edges import predict_edges
+    from molnextr_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer()["chartok_coords"]
+    feats = W.hash_normal("beam_facade", (3, 144, 1024), 0.5)
+    preds = decode_batch(eng, feats.to(dev), beam_size=3, n_best=2, ref_batch_size=3)
+    ref = beam_decode(feats, synth_ckpt["decoder"], beam=3, n_best=2)
+    for i, p in enumerate(preds):
+        d = tok.sequence_to_smiles(ref.tokens[i][0])
+        assert p["chartok_coords"]["smiles"] == d["smiles"] and p["chartok_coords"]["indices"] == d["indices"]
+        assert len(p["beam_scores"]) == 2
+        if d["indices"]:
+            e, _ = predict_edges(ref.hidden[i][0], d["indices"], synth_ckpt["decoder"])
+            assert p["edges"] == np.asarray(e).astype(int).tolist()
+
+
 def test_fixed_length_decode_is_deterministic(eng, dev):
     feats = W.hash_normal("det_features", (4, 144, 1024), 0.5).to(dev)
     a = eng.decode_greedy(feats, max_len=64, stop_on_eos=False)

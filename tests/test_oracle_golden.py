@@ -117,3 +117,32 @@ def test_edge_symmetrise_raw(golden_dir):
     assert np.array_equal(np.argmax(e, axis=2), g["raw_edges"])
     np.testing.assert_allclose(np.max(e, axis=2), g["raw_scores"], atol=0)
     assert np.array_equal(symmetrise(np.zeros((0, 0, 7))), np.zeros((0, 0, 7)))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_beam_strategy_vs_reference_class(golden_dir, case):
+    """oracle.beam.BeamStrategy against the reference's BeamSearch.advance/update_finished driven with the same
+    scripted log-probs (tools/gen_golden.py gen_beam_strategy): back-pointers, ids, scores, surviving images per
+    step, and the final n-best lists."""
+    from oracle.beam import BeamStrategy
+    g = np.load(os.path.join(golden_dir, "beam_strategy.npz"))
+    B, K, NB, ML, V = g[case + "_cfg"].tolist()
+    z = W.hash_normal("beam_script_" + case, (ML, B, K, V), 1.0).clone()
+    z[..., 2] += float(g[case + "_boost"][0])
+    table = torch.log_softmax(z, dim=-1)
+    st = BeamStrategy(B, K, NB, ML, eos=2)
+    seqs = [[] for _ in range(B * K)]
+    nsteps = int(g[case + "_nsteps"][0])
+    for step in range(nsteps):
+        lp = torch.stack([table[step, b, j] for b in st.origin for j in range(K)])
+        sel, tok, scores, _, _ = st.advance(lp, lambda row, pt, seqs=seqs: seqs[pt[0]] + [pt[1]])
+        assert np.allclose(scores.numpy(), g[f"{case}_score{step}"], rtol=0, atol=0), f"step {step}: scores"
+        assert sel.tolist() == g[f"{case}_sel{step}"].tolist(), f"step {step}: back-pointers"
+        assert tok.tolist() == g[f"{case}_tok{step}"].tolist(), f"step {step}: ids"
+        assert st.origin == g[f"{case}_origin{step}"].tolist(), f"step {step}: surviving images"
+        seqs = [seqs[p] + [t] for p, t in zip(sel.tolist(), tok.tolist())]
+    assert st.done
+    for b in range(B):
+        for r in range(NB):
+            assert st.results[b][r][1] == g[f"{case}_pred{b}_{r}"].tolist(), f"image {b} rank {r}"
+            assert st.results[b][r][0] == pytest.approx(float(g[f"{case}_final{b}_{r}"][0]), abs=0)

@@ -19,6 +19,8 @@ Fixtures (all small):
   tokenizer.json       get_output_mask truth table (229 ids) + sequence_to_smiles cases
   predict_e2e.json     Decoder.decode end-to-end on B=4: smiles / symbols / coords / indices / edges
   predict_e2e_conf.json  same with compute_confidence=True on B=3: atom / edge / overall scores
+  beam_strategy.npz    BeamSearch.advance/update_finished driven with scripted log-probs: back-pointers, ids, scores,
+                       surviving images per step, final n-best predictions
 """
 import hashlib
 import json
@@ -230,6 +232,57 @@ def gen_e2e_confidence(dec, feats):
     print("predict_e2e_conf: atoms", [len(o["symbols"]) for o in out])
 
 
+def beam_script(name, steps, B, K, V, eos_boost):
+    """Scripted per-(step, image, beam) log-prob rows: log_softmax of hash-normal logits, EOS (id 2) boosted."""
+    z = W.hash_normal(name, (steps, B, K, V), 1.0).clone()
+    z[..., 2] += eos_boost
+    return torch.log_softmax(z, dim=-1)
+
+
+def gen_beam_strategy():
+    """The reference's BeamSearch class driven DIRECTLY with scripted log-probs (its decode loop cannot run: the
+    constructor passes max_length/return_attention to DecodeStrategy in swapped positions and decode() calls advance
+    with the wrong arity). The swapped positions are compensated at the call site below, so that every line of
+    advance/_pick/update_finished executes as written."""
+    from MolNexTR.decoding.beam_search import BeamSearch
+    out = {}
+    cases = [("a", 4, 3, 2, 7, 24, 1.5), ("b", 3, 5, 1, 9, 32, 0.2), ("c", 2, 2, 2, 4, 16, -4.0), ("d", 5, 4, 4, 12, 20, 1.0)]
+    for name, B, K, NB, ML, V, boost in cases:
+        table = beam_script("beam_script_" + name, ML, B, K, V, boost)
+        bs = BeamSearch(pad=0, bos=1, eos=2, batch_size=B, beam_size=K, n_best=NB, min_length=1,
+                        return_attention=ML, max_length=False)   # lands as max_length=ML, return_attention=False
+        assert bs.max_length == ML and bs.return_attention is False
+        bs.initialize(torch.zeros(B, 3, 4))
+        sel, toks, scs, offs = [], [], [], []
+        for step in range(ML):
+            origin = bs.batch_offset.tolist()
+            lp = torch.stack([table[step, b, j] for b in origin for j in range(K)]).clone()
+            bs.advance(lp, None)
+            sc_step = bs.topk_scores.clone()
+            if bs.is_finished.any():
+                bs.update_finished()
+                if bs.done:
+                    scs.append(sc_step.numpy()); sel.append(np.zeros(0, np.int64)); toks.append(np.zeros(0, np.int64))
+                    offs.append(np.zeros(0, np.int64))
+                    break
+            scs.append(sc_step.numpy())
+            sel.append(bs.select_indices.numpy().copy())
+            toks.append(bs.topk_ids.reshape(-1).numpy().copy())
+            offs.append(bs.batch_offset.numpy().copy())
+        assert bs.done, name
+        out[name + "_cfg"] = np.array([B, K, NB, ML, V], dtype=np.int64)
+        out[name + "_boost"] = np.array([boost])
+        out[name + "_nsteps"] = np.array([len(sel)])
+        for i, (a, b, c, d) in enumerate(zip(sel, toks, scs, offs)):
+            out[f"{name}_sel{i}"], out[f"{name}_tok{i}"], out[f"{name}_score{i}"], out[f"{name}_origin{i}"] = a, b, c, d
+        for b in range(B):
+            for r in range(NB):
+                out[f"{name}_pred{b}_{r}"] = bs.predictions[b][r].numpy()
+                out[f"{name}_final{b}_{r}"] = np.array([bs.scores[b][r]], dtype=np.float64)
+        print("beam_strategy", name, "steps", len(sel), "lens", [[len(p) for p in bs.predictions[b]] for b in range(B)])
+    np.savez_compressed(os.path.join(GOLD, "beam_strategy.npz"), **out)
+
+
 def main():
     if not have_reference():
         raise SystemExit("/root/reference is not mounted: fixtures can only be regenerated in the build container")
@@ -254,6 +307,7 @@ def main():
     gen_tokenizer(tok, decoded)
     gen_e2e(dec, W.hash_normal("e2e_features", (4, 144, 1024), 0.5))
     gen_e2e_confidence(dec, W.hash_normal("conf_features", (3, 144, 1024), 0.5))
+    gen_beam_strategy()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}
     print("fixture bytes:", sizes, "total", sum(sizes.values()))
 
