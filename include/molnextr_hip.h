@@ -144,6 +144,16 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
 int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const int32_t* n_atoms, int32_t B,
               int32_t kmax, int32_t max_len, uint8_t* edges, double* scores, void* stream);
 
+/* The transform in front of the encoder (MolNexTR/dataset.py:158-185 with augment=False; data_aug.py:98-143;
+ * applied per image at model.py:104): CropWhite(pad) -> Resize(img_size, bilinear) -> ToGray -> Normalize -> CHW.
+ *   rgb      device uint8 [height,width,3] (RGB, as cv2.cvtColor(BGR2RGB) leaves it)
+ *   pad      white border added around the ink bounding box (the reference uses 50)
+ *   out      device fp32 [3,img_size,img_size] — one image of mnx_encode's input
+ * Asynchronous on `stream`. Bit-identical to molnextr_amd/preprocess.py (the host restatement of the
+ * albumentations/OpenCV arithmetic; unpinned against the reference). */
+int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t width, int32_t pad, float* out,
+                   void* stream);
+
 /* Token classes for the on-device atom-position scan used by mnx_predict (the 'indices' that
  * CharTokenizer.sequence_to_smiles derives, MolNexTR/tokenization.py:464-515). flags[id]: bit0 = is_symbol(id),
  * bit1 = is_atom(id) for id < n (= number of vocabulary symbols); the ids of '[' ']' 'C' 'l' 'B' 'r'. */

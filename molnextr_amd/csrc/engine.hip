@@ -60,6 +60,7 @@ struct mnx_engine {
     DecBuffers db{};
     float* out_trace = nullptr;
     BeamBuffers beam{};        // allocated lazily on the first mnx_decode_beam
+    int* prep_bbox = nullptr;  // scratch of mnx_preprocess
     int* host_flag = nullptr;  // pinned: [2][1 + MAX_CHUNKS] poll snapshots + slot lists
     std::map<GraphKey, hipGraphExec_t> graphs;
     // continuous-batching pipeline (mnx_predict)
@@ -747,6 +748,20 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
     if (rc != MNX_OK) return rc;
     HIPCHK(h, beam_enqueue_gather(h->db, run, max_len, tokens, lengths, scores, hidden, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    return MNX_OK;
+}
+
+int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t width, int32_t pad, float* out,
+                   void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!rgb || !out || height < 1 || width < 1 || pad < 0) { h->err = "mnx_preprocess: null/empty argument"; return MNX_ERR_INVALID_ARG; }
+    if (height > 16384 || width > 16384 || pad > 4096) { h->err = "mnx_preprocess: image larger than 16384x16384"; return MNX_ERR_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->prep_bbox) {
+        HIPCHK(h, hipMalloc((void**)&h->prep_bbox, 4 * sizeof(int)));
+        h->allocs.push_back(h->prep_bbox);
+    }
+    HIPCHK(h, launch_preprocess(rgb, height, width, pad, h->cfg.img_size, h->prep_bbox, out, (hipStream_t)stream));
     return MNX_OK;
 }
 

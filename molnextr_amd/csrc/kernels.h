@@ -28,6 +28,10 @@ hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_tab
                               int C, int heads, int shift, hipStream_t s);
 hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStream_t s);
 
+// ---- preprocess.hip -------------------------------------------------------------------------
+// HWC uint8 RGB page -> [3,S,S] fp32 (CropWhite(pad) + bilinear resize + gray + ImageNet normalise); bbox: 4 ints scratch
+hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int pad, int S, int* bbox, float* out, hipStream_t s);
+
 // ---- decoder.hip ----------------------------------------------------------------------------
 struct DecWeights;   // device pointers, see engine.cpp
 struct DecState;

@@ -21,7 +21,7 @@ _lib = None
 ABI_VERSION = 1
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
-           "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam")
+           "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess")
 
 
 class MnxConfig(C.Structure):
@@ -83,6 +83,8 @@ def load_library():
     lib.mnx_set_token_classes.argtypes = [vp, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     lib.mnx_atom_scan.restype = C.c_int
     lib.mnx_atom_scan.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.mnx_preprocess.restype = C.c_int
+    lib.mnx_preprocess.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.mnx_decode_beam.restype = C.c_int
     lib.mnx_decode_beam.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.mnx_predict.restype = C.c_int
@@ -218,6 +220,24 @@ class Engine:
                                         _stream())
         self._check(rc, "mnx_decode_greedy")
         return {"tokens": tokens, "lengths": lengths, "token_logp": logp, "hidden": hidden, "logits": trace}
+
+    # -- CropWhite + Resize + ToGray + Normalize on device ---------------------------------------------
+    def preprocess(self, images, pad: int = 50) -> torch.Tensor:
+        """List of HWC uint8 RGB pages (numpy arrays or tensors, any sizes) -> [n,3,S,S] fp32 on the device."""
+        dev = torch.device("cuda", self.device)
+        S = self.enc.img_size
+        out = torch.empty(len(images), 3, S, S, dtype=torch.float32, device=dev)
+        keep = []
+        for i, im in enumerate(images):
+            t = torch.as_tensor(im)
+            if t.dim() == 2:
+                t = t[..., None].expand(-1, -1, 3)
+            t = t[..., :3].to(dtype=torch.uint8).contiguous().to(dev, non_blocking=True)
+            keep.append(t)
+            self._check(self.lib.mnx_preprocess(self.h, _ptr(t), t.shape[0], t.shape[1], pad, _ptr(out[i]), _stream()),
+                        "mnx_preprocess")
+        torch.cuda.current_stream().synchronize()      # the uploaded pages must outlive the kernels
+        return out
 
     # -- TransformerDecoderAR.decode, beam_size > 1 --------------------------------------------------
     def decode_beam(self, features: torch.Tensor, beam: int = 5, n_best: int = 1, max_len: Optional[int] = None,

@@ -124,7 +124,8 @@ class molnextr:
     the deterministic synthetic checkpoint (no pretrained weights exist offline).
     device: torch.device('cuda', i) — an MI355X is required."""
 
-    def __init__(self, model_path=None, device=None, max_batch: int = 32, dtype: str = "bf16"):
+    def __init__(self, model_path=None, device=None, max_batch: int = 32, dtype: str = "bf16",
+                 device_preprocess: bool = True):
         if model_path in (None, "synthetic"):
             states = W.synthetic_checkpoint(0)
         else:
@@ -141,6 +142,7 @@ class molnextr:
         self.engine = Engine(states["encoder"], states["decoder"], device=device.index or 0, max_batch=max_batch,
                              dtype=dtype)
         self.input_size = args.input_size
+        self.device_preprocess = device_preprocess
 
     @staticmethod
     def _get_args(args_states=None):
@@ -155,20 +157,25 @@ class molnextr:
             raise NotImplementedError("engine is built for the swin_base / 384 / discrete-coordinate configuration")
         return a
 
+    def _transform(self, images: List) -> torch.Tensor:
+        """CropWhite + Resize + ToGray + Normalize (reference model.py:104): on the device (mnx_preprocess), or with the
+        bit-identical host restatement when `device_preprocess` is off."""
+        if self.device_preprocess:
+            return self.engine.preprocess(images)
+        return torch.from_numpy(np.stack([transform_image(im, self.input_size) for im in images])).to(self.device)
+
     def predict_images(self, input_images: List, return_atoms_bonds=False, return_confidence=False, batch_size=16):
         preds: List[dict] = []
         batch_size = min(batch_size, ROWS, self.engine.max_batch)
         if not return_confidence:
             # throughput path: all images at once, reference batches of `batch_size` kept as numbering units
             for i in range(0, len(input_images), 1024):
-                imgs = [transform_image(im, self.input_size) for im in input_images[i:i + 1024]]
-                x = torch.from_numpy(np.stack(imgs)).to(self.device)
+                x = self._transform(input_images[i:i + 1024])
                 preds += predict_pipeline(self.engine, x, self.tokenizer, ref_batch_size=batch_size)
         else:
             step = max(self.engine.max_batch // batch_size, 1) * batch_size
             for i in range(0, len(input_images), step):
-                imgs = [transform_image(im, self.input_size) for im in input_images[i:i + step]]
-                x = torch.from_numpy(np.stack(imgs)).to(self.device)
+                x = self._transform(input_images[i:i + step])
                 feats = self.engine.encode(x)
                 preds += decode_batch(self.engine, feats, self.tokenizer, ref_batch_size=batch_size,
                                       compute_confidence=True)

@@ -5,7 +5,8 @@
 
 The reference runs these through albumentations 1.1.0 / OpenCV, neither of which is installed here; they are
 restated from their documented behaviour: `cv2.resize(INTER_LINEAR)` on uint8 = half-pixel-centre bilinear with
-11-bit fixed-point weights; `cv2.cvtColor(RGB2GRAY)` = (R*4899 + G*9617 + B*1868 + 8192) >> 14; Normalize =
+11-bit fixed-point weights and OpenCV's two-pass integer arithmetic (its 2x-decimation special case, which
+switches to area averaging for exact integer scale 2, is NOT restated); `cv2.cvtColor(RGB2GRAY)` = (R*4899 + G*9617 + B*1868 + 8192) >> 14; Normalize =
 (x/255 - mean) / std. PARITY UNPINNED until a box with OpenCV can produce fixtures.
 """
 import numpy as np
@@ -37,28 +38,33 @@ def crop_white(img: np.ndarray, pad: int = 50, value=(255, 255, 255)) -> np.ndar
 
 
 def _linear_coeffs(src: int, dst: int):
-    """cv2 INTER_LINEAR sampling: fx = (dx+0.5)*scale-0.5, clamped; weights quantised to 11 bits."""
-    scale = src / dst
-    fx = (np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5
+    """cv2.resize(INTER_LINEAR) sampling for 8-bit images: fx = (float)((dx+0.5)*scale-0.5) with a double `scale`
+    = 1/(dst/src), source index clamped to [0, src-1] with the fraction zeroed at the borders, and BOTH weights
+    rounded to 11 bits on their own (saturate_cast<short>(w * 2048), round-half-even)."""
+    scale = 1.0 / (float(dst) / float(src))
+    fx = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     sx = np.floor(fx).astype(np.int64)
-    frac = fx - sx
+    frac = (fx - sx.astype(np.float32)).astype(np.float32)
     frac[sx < 0] = 0.0
     sx[sx < 0] = 0
     over = sx >= src - 1
     frac[over] = 0.0
     sx[over] = src - 1
-    w1 = np.rint(frac * 2048).astype(np.int64)
-    return sx, np.minimum(sx + 1, src - 1), 2048 - w1, w1
+    w0 = np.rint((np.float32(1.0) - frac) * np.float32(2048.0)).astype(np.int64)
+    w1 = np.rint(frac * np.float32(2048.0)).astype(np.int64)
+    return sx, np.minimum(sx + 1, src - 1), w0, w1
 
 
 def resize_bilinear_u8(img: np.ndarray, size: int) -> np.ndarray:
+    """Two-pass fixed point as OpenCV's 8-bit linear resize: horizontal sums keep 11 fractional bits, the vertical
+    pass computes ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16), adds 2 and shifts by 2."""
     h, w, _ = img.shape
     y0, y1, wy0, wy1 = _linear_coeffs(h, size)
     x0, x1, wx0, wx1 = _linear_coeffs(w, size)
     im = img.astype(np.int64)
-    rows = im[y0][:, x0] * wx0[None, :, None] + im[y0][:, x1] * wx1[None, :, None]
-    rows2 = im[y1][:, x0] * wx0[None, :, None] + im[y1][:, x1] * wx1[None, :, None]
-    out = (rows * wy0[:, None, None] + rows2 * wy1[:, None, None] + (1 << 21)) >> 22
+    r0 = im[y0][:, x0] * wx0[None, :, None] + im[y0][:, x1] * wx1[None, :, None]
+    r1 = im[y1][:, x0] * wx0[None, :, None] + im[y1][:, x1] * wx1[None, :, None]
+    out = (((wy0[:, None, None] * (r0 >> 4)) >> 16) + ((wy1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
     return np.clip(out, 0, 255).astype(np.uint8)
 
 

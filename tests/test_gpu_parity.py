@@ -464,6 +464,30 @@ def test_public_api_predict_images_synthetic(dev):
     m.engine.close()
 
 
+def test_device_preprocess_is_bit_identical_to_host_restatement(eng, dev):
+    """mnx_preprocess (bounding box + virtual white border + fixed-point bilinear + gray + normalise) against
+    molnextr_amd/preprocess.py on ragged pages: blank, 1x1, ink on the borders, upscaling, strong decimation."""
+    from molnextr_amd.preprocess import transform_image
+    rng = np.random.default_rng(7)
+    pages = []
+    for (h, w) in [(470, 923), (64, 64), (1, 1), (37, 911), (1500, 2000), (384, 384), (300, 17)]:
+        img = np.full((h, w, 3), 255, np.uint8)
+        for _ in range(12):       # random coloured strokes, some touching the page border
+            y, x = rng.integers(0, h), rng.integers(0, w)
+            hh, ww = rng.integers(1, max(2, h // 3)), rng.integers(1, max(2, w // 3))
+            img[y:y + hh, x:x + ww] = rng.integers(0, 256, size=3, dtype=np.uint8)
+        pages.append(img)
+    pages.append(np.full((50, 70, 3), 255, np.uint8))                       # blank page: no crop, border only
+    pages.append(rng.integers(0, 256, size=(200, 333, 3), dtype=np.uint8))  # noise: exercises every weight pair
+    pages.append(rng.integers(0, 256, size=(90, 120), dtype=np.uint8))      # single-channel input
+    edge = np.full((40, 40, 3), 255, np.uint8); edge[0, 0] = 0; edge[-1, -1] = 254
+    pages.append(edge)
+    out = eng.preprocess(pages).cpu().numpy()
+    for i, p in enumerate(pages):
+        ref = transform_image(p)
+        assert np.array_equal(out[i], ref), f"page {i} {p.shape}: {np.abs(out[i] - ref).max()}"
+
+
 def test_capacity_and_argument_errors(eng, dev):
     from molnextr_amd.engine import MnxError
     with pytest.raises(MnxError, match="32"):
