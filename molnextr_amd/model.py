@@ -129,7 +129,8 @@ class molnextr:
         if model_path in (None, "synthetic"):
             states = W.synthetic_checkpoint(0)
         else:
-            states = torch.load(model_path, map_location=torch.device("cpu"))
+            from .checkpoint import load_checkpoint      # .pth in the reference format or our .safetensors; strict
+            states = load_checkpoint(model_path)
         args = self._get_args(states.get("args"))
         if device is None:
             device = torch.device("cuda", 0)

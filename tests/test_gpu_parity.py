@@ -488,6 +488,37 @@ def test_device_preprocess_is_bit_identical_to_host_restatement(eng, dev):
         assert np.array_equal(out[i], ref), f"page {i} {p.shape}: {np.abs(out[i] - ref).max()}"
 
 
+def test_eval_harness_reproduces_reference_batches(eng, dev, tmp_path):
+    """molnextr_amd.evaluate.run_inference on image files: DistributedSampler-style shard (world 1 and a simulated
+    rank of world 2), per-rank batches of batch_size*2 as reference batches, records -> prediction dicts; must equal the
+    per-batch engine path on the same batches."""
+    from PIL import Image
+    from molnextr_amd import evaluate as E
+    from molnextr_amd.preprocess import load_image_rgb
+    from molnextr_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer()["chartok_coords"]
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(11):
+        page = np.full((120 + 10 * i, 200, 3), 255, np.uint8)
+        for _ in range(10):
+            y, x = rng.integers(0, 100), rng.integers(0, 180)
+            page[y:y + rng.integers(1, 20), x:x + rng.integers(1, 20)] = 0
+        paths.append(str(tmp_path / f"p{i}.png"))
+        Image.fromarray(page).save(paths[-1])
+    load = lambda i: load_image_rgb(paths[i])
+    preds = E.run_inference(eng, load, len(paths), batch_size=2)
+    assert sorted(preds) == list(range(11))
+    for b in E.reference_batches(E.sampler_indices(11, 0, 1), batch_size=2):     # batches of 4, 4, 3
+        feats = eng.encode(eng.preprocess([load(i) for i in b]))
+        out = eng.decode_greedy(feats)
+        for r, i in enumerate(b):
+            n = int(out["lengths"][r])
+            assert preds[i]["chartok_coords"]["smiles"] == tok.sequence_to_smiles(out["tokens"][r, :n].cpu().tolist())["smiles"]
+    table = E.predictions_table([f"p{i}" for i in range(11)], preds)
+    assert len(table["SMILES"]) == 11 and table["edges"][0].startswith("[")
+
+
 def test_capacity_and_argument_errors(eng, dev):
     from molnextr_amd.engine import MnxError
     with pytest.raises(MnxError, match="32"):

@@ -55,3 +55,28 @@ def test_synthetic_images_shape_and_range():
     assert x.shape == (2, 3, 384, 384) and x.dtype == torch.float32
     assert float(x.max()) <= (1 - 0.406) / 0.225 + 1e-5 and float(x.min()) >= -0.485 / 0.229 - 1e-5
     assert torch.equal(x[1], W.synthetic_images(1, first_index=1)[0])
+
+
+def test_checkpoint_convert_roundtrip_and_strictness(tmp_path):
+    """Reference-format .pth (with training state and DDP 'module.' prefixes) -> safetensors -> identical tensors;
+    a checkpoint with a missing / mis-shaped tensor is rejected instead of being loaded with strict=False."""
+    import torch
+    from molnextr_amd import checkpoint as C
+    ck = W.synthetic_checkpoint(0)
+    pth = {"encoder": {"module." + k: v for k, v in ck["encoder"].items()}, "decoder": dict(ck["decoder"]),
+           "optimizer": {"state": {}}, "scheduler": {}, "global_step": 7,
+           "args": {"formats": ["chartok_coords", "edges"], "input_size": 384, "coord_bins": 64, "sep_xy": True}}
+    src, dst = str(tmp_path / "ref.pth"), str(tmp_path / "ref.safetensors")
+    torch.save(pth, src)
+    info = C.convert(src, dst)
+    assert info["tensors"] == len(ck["encoder"]) + len(ck["decoder"])
+    back = C.load_checkpoint(dst)
+    assert back["args"]["coord_bins"] == 64 and set(back) == {"encoder", "decoder", "args"}
+    for part in ("encoder", "decoder"):
+        assert list(back[part]) and all(torch.equal(back[part][k], ck[part][k]) for k in ck[part])
+    bad = dict(pth)
+    bad["decoder"] = {k: v for k, v in ck["decoder"].items() if "output_layer.bias" not in k}
+    torch.save(bad, src)
+    import pytest
+    with pytest.raises(ValueError, match="output_layer.bias"):
+        C.load_checkpoint(src)
