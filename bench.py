@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "64")),
                     help="images per encoder launch group (a multiple of 32; decode batches stay 32)")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("MNX_SLOTS", "3072")),
+                    help="sequences resident in the decoder (multiple of 32, <= 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL record gather even with one rank")
     args = ap.parse_args()
@@ -133,7 +135,8 @@ def main():
 
     ck = W.synthetic_checkpoint(0)
     tok = get_tokenizer()["chartok_coords"]
-    eng = Engine(ck["encoder"], ck["decoder"], device=local, max_batch=max(BATCH, args.encode_batch), dtype=args.dtype)
+    eng = Engine(ck["encoder"], ck["decoder"], device=local, max_batch=max(BATCH, args.encode_batch), dtype=args.dtype,
+                 dec_slots=args.slots)
     kmax = eng.max_atoms
     # step s, rank r owns images [(s*world + r)*32, +32): every step has its own images (8 distinct batches cycle)
     n_distinct = 8
@@ -240,7 +243,7 @@ def main():
                                    f"decode to EOS (max_length {args.max_len}) + atom positions + bond head"
                                    + (", RCCL all-gather of result records" if world > 1 else ""),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world,
-                       "mode": ("continuous batching: up to 64 reference batches (2048 sequences) resident in the decoder"
+                       "mode": (f"continuous batching: up to {args.slots // 32} reference batches ({args.slots} sequences) resident in the decoder"
                                 if args.mode == "pipeline" else "one batch at a time"),
                        "decoded_len_mean": round(float(np.mean(stats["lens"])), 1),
                        "decoded_len_max": int(np.max(stats["lens"])),

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MNX_ABI_VERSION 1
+#define MNX_ABI_VERSION 2
 
 typedef struct mnx_engine mnx_engine;
 
@@ -59,6 +59,7 @@ typedef struct {
     int32_t max_batch;       /* images per mnx_encode call the workspace is sized for */
     int32_t max_atoms;       /* kmax of mnx_edges (<= max_len / 3) */
     int32_t compute_dtype;   /* MNX_DTYPE_BF16 */
+    int32_t dec_slots;       /* sequences resident in the decoder during mnx_predict: multiple of 32, <= 4096; 0 = 2048 */
 } mnx_config;
 
 /* One named fp32 tensor of the checkpoint, in HOST memory. Names are the reference state-dict keys

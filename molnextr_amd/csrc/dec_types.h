@@ -5,11 +5,11 @@
 
 namespace mnx {
 
-constexpr int MAX_SLOTS = 2048;    // sequence state slots resident on the GPU (64 reference batches of 32)
+constexpr int MAX_SLOTS = 4096;    // capacity of the sequence-state arrays (cfg.dec_slots <= this; default 2048 in use)
 constexpr int BEGIN_THREADS = 1024;
 constexpr int ROW_TILE = 32;       // rows per workgroup of the skinny linears; also the max reference batch
 constexpr int MAX_DEC_LAYERS = 8;
-constexpr int MAX_CHUNKS = 64;     // reference batches in flight (slots of one batch may be scattered)
+constexpr int MAX_CHUNKS = 128;    // reference batches in flight (slots of one batch may be scattered)
 
 // Decode state of every slot; lives in device memory and is advanced by the tick graph itself.
 // A "slot" is one sequence being decoded. Slots of one reference batch ("chunk") share a positional-encoding

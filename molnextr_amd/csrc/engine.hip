@@ -190,6 +190,7 @@ int check_cfg(const mnx_config& c, std::string& why) {
     if (c.max_batch < 1) return bad("max_batch < 1");
     if (c.max_atoms < 1 || c.max_atoms > 256) return bad("max_atoms must be 1..256");
     if (c.compute_dtype != MNX_DTYPE_BF16 && c.compute_dtype != MNX_DTYPE_FP16) return bad("compute_dtype");
+    if (c.dec_slots < 0 || c.dec_slots > MAX_SLOTS || (c.dec_slots % ROW_TILE) != 0) return bad("dec_slots");
     if (c.pe_len < ROW_TILE) return bad("pe_len too small");
     return MNX_OK;
 }
@@ -448,7 +449,7 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->attn16 = P.dalloc(MB * max_xn * 2);
     h->h16 = P.dalloc(MB * max_h * 2);
     DecBuffers& db = h->db;
-    const int SL = MAX_SLOTS;
+    const int SL = c.dec_slots > 0 ? c.dec_slots : 2048;
     h->n_chunk_bufs = SL / ROW_TILE;   // one reference batch per 32-slot row tile
     db.T = c.max_len; db.S = (int)S; db.slots = SL; db.mem_blocks = h->n_chunk_bufs * ROW_TILE; db.kmax = c.max_atoms;
     db.st = (DecState*)P.dalloc(sizeof(DecState));
@@ -827,7 +828,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         HIPCHK(h, hipStreamWaitEvent(h->dec_stream, h->ev_order, 0));
         s = h->dec_stream;
     }
-    const int S = h->db.S, D = c.dec_dim, SL = MAX_SLOTS;
+    const int S = h->db.S, D = c.dec_dim, SL = h->db.slots;
     const size_t img_elems = (size_t)3 * c.img_size * c.img_size;
     const int n_chunks = (n_img + ref_batch - 1) / ref_batch;
     struct Chunk { int first, n, tag, admit_seq; std::vector<int> slots; };
@@ -912,7 +913,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         if (live.empty()) continue;       // (only possible before the first admission)
         // ---- a group of ticks, then a status snapshot
         // launch the tick graph sized for the alive-row bound (dense active list: idle row tiles are not launched)
-        static const int caps[] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048};
+        static const int caps[] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096};
         int rows_cap = SL;
         for (int cp : caps) if (cp >= bound) { rows_cap = cp; break; }
         hipGraphExec_t exec = nullptr;

@@ -18,7 +18,7 @@ from . import weights as W
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmolnextr_hip.so")
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
            "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess")
@@ -30,7 +30,7 @@ class MnxConfig(C.Structure):
                 ("dec_layers", C.c_int32), ("dec_dim", C.c_int32), ("dec_heads", C.c_int32), ("dec_ff", C.c_int32),
                 ("vocab", C.c_int32), ("sym_offset", C.c_int32), ("coord_bins", C.c_int32), ("pe_len", C.c_int32),
                 ("max_len", C.c_int32), ("max_batch", C.c_int32), ("max_atoms", C.c_int32),
-                ("compute_dtype", C.c_int32)]
+                ("compute_dtype", C.c_int32), ("dec_slots", C.c_int32)]
 
 
 class MnxWeightDesc(C.Structure):
@@ -110,7 +110,7 @@ class Engine:
 
     def __init__(self, encoder_state: Dict[str, torch.Tensor], decoder_state: Dict[str, torch.Tensor],
                  device: int = 0, max_batch: int = 32, enc: W.EncoderDims = W.SWIN_B, dec: W.DecoderDims = W.DEC,
-                 dtype: str = "bf16", max_len: int = 480, max_atoms: int = 160):
+                 dtype: str = "bf16", max_len: int = 480, max_atoms: int = 160, dec_slots: int = 2048):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise MnxError("no HIP device visible: molnextr_amd needs an MI355X (gfx950); there is no CPU fallback")
@@ -133,6 +133,7 @@ class Engine:
         cfg.vocab, cfg.sym_offset, cfg.coord_bins, cfg.pe_len = dec.vocab, dec.vocab - 128, 64, dec.pe_len
         cfg.max_len, cfg.max_batch, cfg.max_atoms = max_len, max_batch, max_atoms
         cfg.compute_dtype = {"bf16": 0, "fp16": 1}[dtype]
+        cfg.dec_slots = dec_slots
         self.dtype = dtype
         keep, descs = [], []
         for state in (encoder_state, decoder_state):

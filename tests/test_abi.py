@@ -28,12 +28,12 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.mnx_abi_version() == engine.ABI_VERSION == 1
+    assert lib.mnx_abi_version() == engine.ABI_VERSION == 2
 
 
 def test_config_struct_layout_matches_header():
-    # 19 int32 fields + two int32[4] arrays = 25 int32
-    assert ctypes.sizeof(engine.MnxConfig) == 25 * 4
+    # 20 int32 fields + two int32[4] arrays = 26 int32
+    assert ctypes.sizeof(engine.MnxConfig) == 26 * 4
     assert ctypes.sizeof(engine.MnxWeightDesc) == 8 + 8 + 8 + 32
 
 
