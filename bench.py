@@ -159,8 +159,12 @@ def main():
             out = eng.predict(imgs, ref_batch=BATCH, max_len=args.max_len)
             stats["lens"] = out["lengths"].cpu().numpy()
             stats["atoms"] = out["n_atoms"].cpu().numpy()
-            rec = shard.pack_records_device(out["tokens"], out["lengths"], out["atom_idx"], out["n_atoms"], out["edges"]) \
-                if args.max_len == shard.MAX_LEN else None
+            rec = None
+            if args.max_len == shard.MAX_LEN:
+                # records sized by the largest molecule of the whole job (one scalar all-reduce), not by max_atoms
+                k = shard.common_atom_capacity(out["n_atoms"], kmax)
+                ai, ed = shard.trim_atoms(out["atom_idx"], out["edges"], k)
+                rec = shard.pack_records_device(out["tokens"], out["lengths"], ai, out["n_atoms"], ed)
         else:
             recs, lens, atoms = [], [], []
             for i in range(count):
@@ -175,12 +179,10 @@ def main():
                 rec = shard.gather_records(rec, force=args.force_gather)
             # results land in pinned host memory: every rank keeps its own shard, rank 0 the gathered whole
             mine = rec if (rank == 0 or world == 1) else rec[rank * count * BATCH:(rank + 1) * count * BATCH]
-            key = tuple(mine.shape)
-            if key not in host_buf:
-                host_buf[key] = torch.empty(mine.shape, dtype=mine.dtype, pin_memory=True)
-            host_buf[key].copy_(mine, non_blocking=True)
+            land = host_buf["pinned"][:mine.numel()].view(mine.shape)
+            land.copy_(mine, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            rec = host_buf[key]
+            rec = land
         return rec
 
     def barrier():
@@ -189,13 +191,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # pinned landing buffer for the result records, allocated once outside the timed region (capacity: every record
+    # at the engine's max_atoms; the records actually exchanged are sized by the largest molecule of the job)
+    gathered = world if (rank == 0 and (world > 1 or args.force_gather)) else 1
+    host_buf["pinned"] = torch.empty(max(args.steps, args.warmup) * BATCH * gathered * shard.record_words(kmax),
+                                     dtype=torch.int32, pin_memory=True)
     imgs = run(0, args.warmup)
     process(imgs, args.warmup)
     imgs = run(args.warmup, args.steps)
-    if args.max_len == shard.MAX_LEN:   # pinned landing buffer of the timed call, allocated outside the timed region
-        rows = args.steps * BATCH * (world if (rank == 0 and (world > 1 or args.force_gather)) else 1)
-        host_buf[(rows, shard.record_words(kmax))] = torch.empty((rows, shard.record_words(kmax)), dtype=torch.int32,
-                                                                 pin_memory=True)
     barrier()
     t0 = time.perf_counter()
     process(imgs, args.steps)

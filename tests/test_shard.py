@@ -56,8 +56,18 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     kmax = 23
     lo, hi = shard.shard_range(8, rank, world)
-    rec = shard.pack_records(*_fake_results(lo, hi, kmax), kmax)
+    tokens, lengths, atom_idx, n_atoms, edges = _fake_results(lo, hi, kmax)
+    rec = shard.pack_records(tokens, lengths, atom_idx, n_atoms, edges, kmax)
     allrec = shard.gather_records(rec)
+    # records sized by the largest molecule of the job: both ranks must agree on the capacity (scalar all-reduce MAX)
+    k = shard.common_atom_capacity(torch.from_numpy(n_atoms), 23)
+    ai, ed = shard.trim_atoms(torch.from_numpy(atom_idx), torch.from_numpy(edges), k)
+    small = shard.gather_records(shard.pack_records(tokens, lengths, ai.numpy(), n_atoms, ed.numpy(), k))
+    full_atoms = _fake_results(0, 8, 23)[3]
+    assert k == min(23, max(4, (int(full_atoms.max()) + 3) // 4 * 4)), "capacity must be the job-wide maximum"
+    assert [d["edges"] for d in shard.unpack_records(small, k)] == [d["edges"] for d in shard.unpack_records(allrec, 23)]
+    assert [d["atom_idx"] for d in shard.unpack_records(small, k)] == \
+        [d["atom_idx"] for d in shard.unpack_records(allrec, 23)]
     dist.barrier()
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the max-over-ranks timing reduction bench.py uses
