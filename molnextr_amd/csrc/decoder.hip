@@ -7,6 +7,8 @@
 // so the whole step is a fixed hipGraph that the host replays (engine.cpp). Batch rows are fixed slots; a
 // finished row keeps its slot (no compaction on device) and the reference's row renumbering is emulated only
 // where it is observable: the positional-encoding row (see embed prologue).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "dec_types.h"
@@ -203,6 +205,153 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     const int row = row0 + lrow;                      // activations of this tick are per active-list row
     if (!live) return;
     const int nc = part * 4;                          // 4 consecutive output columns per thread
+    f32x4 v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        v[u] = (red[(0 * 32 + lrow) * 33 + nc + u] + red[(1 * 32 + lrow) * 33 + nc + u]) +
+               (red[(2 * 32 + lrow) * 33 + nc + u] + red[(3 * 32 + lrow) * 33 + nc + u]);
+    const int n = n0 + nc;
+    v += *(const f32x4*)(a.bias + n);
+    if (EPI == 0) {
+        const int part_ = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
+        if (part_ == 0) {
+            *(f32x4*)(a.out + (size_t)row * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
+        } else {
+            float* cache = part_ == 1 ? a.kcache : a.vcache;
+            *(f32x4*)(cache + (((size_t)slot * a.heads + hd) * a.T + a.st->t[slot]) * 32 + d) = v;
+        }
+    } else if (EPI == 1) {
+        float* o = a.out + (size_t)row * a.N + n;
+        *(f32x4*)o = *(const f32x4*)o + v;
+    } else if (EPI == 2) {
+        *(f32x4*)(a.out + (size_t)row * a.N + n) = v * 0.17677669529663687f;
+    } else {
+        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        *(f32x4*)(a.out + (size_t)row * a.N + n) = v;
+    }
+}
+
+// Second form of the skinny linear: same tile (32 active rows x 32 output columns, K split over the 4 waves, fp32 MFMA
+// 16x16x4) but the operands go from global memory STRAIGHT into the MFMA register layout — lane (fr, fg) of wave w
+// loads the float4 at [row fr][64 w + 16 kc + 4 fg], which is exactly the fragment the staged form read back from LDS.
+// No LDS staging pass and 17 KB of LDS instead of 66 KB (only the cross-wave reduction and the LayerNorm partial sums
+// go through LDS), so these latency-bound workgroups fit next to two resident encoder GEMM workgroups on a CU.
+// Measured: parity-identical, but 0.8 % SLOWER end to end than the staged form (2743 vs 2765 molecules/s, A/B/A/B):
+// the 64-byte row segments of the fragment loads cost more than the LDS pass saves. Kept behind MNX_DEC_LINEAR_DIRECT.
+// LayerNorm: two-pass, the row statistics are combined over the 4 lane groups (shuffles) and the 4 waves (LDS).
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void dec_linear_direct_kernel(LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
+    __shared__ float s_part[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * TN;
+    const int row0 = blockIdx.y * ROW_TILE;
+    const int n_act = a.st->n_active;
+    if (row0 >= n_act) return;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kq = wave * 64 + fg * 4;               // this lane's k offset inside a 256-wide K chunk (+ 16 kc)
+    bool live[2];
+    int slot_[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        live[rt] = row0 + rt * 16 + fr < n_act;
+        slot_[rt] = live[rt] ? a.st->active[row0 + rt * 16 + fr] : 0;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < a.K; k0 += 256) {
+        f32x4 xa[2][4], wb[2][4];
+        // ---- all loads of the chunk in flight at once ----
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float* wsrc = a.W + (size_t)(n0 + ct * 16 + fr) * a.K + k0 + kq;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) wb[ct][kc] = *(const f32x4*)(wsrc + 16 * kc);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            if (PRO == 2) {
+                // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
+                const float* e = a.emb + (size_t)a.st->prev_tok[slot_[rt]] * 256 + kq;
+                const float* p = a.pe + (size_t)a.st->rank[slot_[rt]] * 256 + kq;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+                    xa[rt][kc] = live[rt] ? *(const f32x4*)(e + 16 * kc) * 16.0f + *(const f32x4*)(p + 16 * kc) : zero4;
+            } else {
+                const float* src = a.in + (size_t)(row0 + rt * 16 + fr) * a.K + k0 + kq;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) xa[rt][kc] = live[rt] ? *(const f32x4*)(src + 16 * kc) : zero4;
+            }
+        }
+        if (PRO == 2 && blockIdx.x == 0) {           // residual stream x = embedding, written once per row
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                if (live[rt]) {
+                    float* dst = a.x_write + (size_t)(row0 + rt * 16 + fr) * 256 + kq;
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) *(f32x4*)(dst + 16 * kc) = xa[rt][kc];
+                }
+        }
+        if (PRO != 0) {                              // LayerNorm over the 256-wide row (K == 256), eps 1e-6
+            float mean[2], rstd[2];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        if (pass == 1) xa[rt][kc] -= mean[rt];
+                        const f32x4 v = xa[rt][kc];
+                        s += pass == 0 ? (v[0] + v[1]) + (v[2] + v[3]) : (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
+                    s += __shfl_xor(s, 16, 64);
+                    s += __shfl_xor(s, 32, 64);
+                    if (fg == 0) s_part[wave][rt * 16 + fr] = s;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int r = rt * 16 + fr;
+                    const float t = (s_part[0][r] + s_part[1][r]) + (s_part[2][r] + s_part[3][r]);
+                    if (pass == 0) mean[rt] = t * (1.0f / 256.0f);
+                    else rstd[rt] = rsqrtf(t * (1.0f / 256.0f) + 1e-6f);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const f32x4 g = *(const f32x4*)(a.gamma + kq + 16 * kc), b = *(const f32x4*)(a.beta + kq + 16 * kc);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) xa[rt][kc] = xa[rt][kc] * rstd[rt] * g + b;
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][kc][j], wb[0][kc][j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][kc][j], wb[1][kc][j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][kc][j], wb[0][kc][j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][kc][j], wb[1][kc][j], acc[1][1], 0, 0, 0);
+            }
+    }
+    // cross-wave reduction through LDS: red[wave][row][col], D layout: lane holds rows fg*4+r, column fr
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * 32 + mt * 16 + fg * 4 + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
+    __syncthreads();
+    const int lrow = tid >> 3, part = tid & 7;       // epilogue mapping: 8 threads per row, 4 columns each
+    if (row0 + lrow >= n_act) return;
+    const int slot = a.st->active[row0 + lrow];
+    const int row = row0 + lrow;
+    const int nc = part * 4;
     f32x4 v;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -497,7 +646,9 @@ __global__ void dec_admit_kernel(DecState* st, const int* slots, const int* rowc
 // ---- host-side enqueue helpers (engine.hip captures the tick into a hipGraph) -----------------
 template <int PRO, int EPI>
 static void lin(hipStream_t s, const LinArgs& a, int slots) {
-    hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
+    static const bool staged = getenv("MNX_DEC_LINEAR_DIRECT") == nullptr;   // A/B knob: the LDS-free form (-0.8 %)
+    if (staged) hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dec_linear_direct_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
 }
 
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s) {
