@@ -58,7 +58,7 @@ struct DecBuffers {
     float *x, *q, *ctx, *h;                    // [slots,256] x3, [slots,1024]
     float *self_k, *self_v;                    // [layers, slots, heads, T, 32]
     float *memory;                             // [32*S, 256]   scratch of one admission
-    float *mem_kv;                             // [mem_blocks, S, layers*512]
+    float *mem_kv;                             // [mem_blocks, layers, K|V, heads, S, 32]
     int* tokens;                               // [slots, T]
     float* logp;                               // [slots, T]
     float* hidden;                             // [slots, T, 256]

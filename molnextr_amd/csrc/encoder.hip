@@ -229,7 +229,7 @@ constexpr int VT_STRIDE = 168;   // elements per V^T row in LDS (336 B: conflict
 template <typename T, int QT>   // QT query tiles (of 16) per wave; 9 / QT waves per workgroup
 __global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __restrict__ qkv,
                                                                   const float* __restrict__ table, T* __restrict__ out,
-                                                                  int H, int W, int C, int heads, int shift) {
+                                                                  int H, int W, int C, int heads, int shift, int xcd) {
     constexpr int NTHR = 64 * 9 / QT;
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
@@ -241,7 +241,9 @@ __global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __res
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nWw = W / WS, nWh = H / WS;
-    int bid = blockIdx.x;
+    // XCD-aware: the heads of one window are consecutive ids, and consecutive ids share an XCD (= an L2), so the two
+    // heads that share every 128-byte line of q / k / v / out hit the same L2 instead of fetching the line twice
+    int bid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int head = bid % heads; bid /= heads;
     const int wx = bid % nWw; bid /= nWw;
     const int wy = bid % nWh;
@@ -366,10 +368,11 @@ hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_tab
                               int C, int heads, int shift, hipStream_t s) {
     if (C != heads * HD || H % WS || W % WS) return hipErrorInvalidValue;
     static const int qt = getenv("MNX_ATTN_QT") ? atoi(getenv("MNX_ATTN_QT")) : 1;
+    static const int xcd = getenv("MNX_ATTN_NO_XCD") ? 0 : 1;
     dim3 grid(B * (H / WS) * (W / WS) * heads);
 #define MNX_ATTN(TT, Q)                                                                                              \
     hipLaunchKernelGGL((window_attn_kernel<TT, Q>), grid, dim3(64 * 9 / Q), 0, s, (const TT*)qkv16, rel_table,      \
-                       (TT*)out16, H, W, C, heads, shift)
+                       (TT*)out16, H, W, C, heads, shift, xcd)
     if (dtype == MNX_DT_F16) { if (qt == 3) MNX_ATTN(f16_t, 3); else MNX_ATTN(f16_t, 1); }
     else { if (qt == 3) MNX_ATTN(bf16_t, 3); else MNX_ATTN(bf16_t, 1); }
 #undef MNX_ATTN

@@ -644,7 +644,7 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
     const int S = h->db.S, D = c.dec_dim;
     // enc_transform, then the cross-attention K/V of all layers in one SGEMM (memory block i = row i)
     HIPCHK(h, launch_sgemm_tn(features, h->dw.w_enc, h->dw.b_enc, h->db.memory, B * S, D, h->dw.enc_dim, s));
-    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s));
+    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s, S));
     HIPCHK(h, dec_enqueue_reset(h->db, s));
     HIPCHK(h, dec_enqueue_admit_rows(h->db, chunk_id, B, max_len, stop_on_eos, s));
     float* trace = nullptr;
@@ -711,7 +711,7 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
     BeamBuffers run = bm;
     if (!hidden) run.phid = nullptr;
     HIPCHK(h, launch_sgemm_tn(features, h->dw.w_enc, h->dw.b_enc, h->db.memory, B * S, D, h->dw.enc_dim, s));
-    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s));
+    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s, S));
     HIPCHK(h, dec_enqueue_reset(h->db, s));
     HIPCHK(h, beam_enqueue_init(h->db, run, max_len, s));
     const int rows = (B * beam + ROW_TILE - 1) / ROW_TILE * ROW_TILE;
@@ -894,7 +894,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             float* memkv = h->db.mem_kv + (size_t)ck.tag * ROW_TILE * S * c.dec_layers * 2 * D;
             const float* feats = h->feat_ring[fb] + (size_t)(next - fb_first[fb]) * ref_batch * S * h->dw.enc_dim;
             HIPCHK(h, launch_sgemm_tn(feats, h->dw.w_enc, h->dw.b_enc, h->db.memory, n * S, D, h->dw.enc_dim, s));
-            HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, memkv, n * S, c.dec_layers * 2 * D, D, s));
+            HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, memkv, n * S, c.dec_layers * 2 * D, D, s, S));
             if (next + 1 == fb_first[fb] + fb_count[fb]) {    // last reference batch of the group: buffer is free again
                 HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
                 feat_used[fb] = true;

@@ -36,6 +36,6 @@ hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int pad, int S, i
 struct DecWeights;   // device pointers, see engine.cpp
 struct DecState;
 hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
-                           hipStream_t s);
+                           hipStream_t s, int perm_S = 0);
 
 }  // namespace mnx
