@@ -857,7 +857,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     const int grp = std::max(1, c.max_batch / ref_batch);
     int fb_first[2] = {-1, -1}, fb_count[2] = {0, 0};   // chunks [first, first+count) live in feature buffer i
     bool feat_used[2] = {false, false};
-    const int ticks_per_poll = 4;
+    static const int ticks_per_poll = getenv("MNX_TICKS_PER_POLL") ? std::max(1, atoi(getenv("MNX_TICKS_PER_POLL"))) : 4;
     while (done < n_chunks) {
         // ---- encoder prefetch: keep both feature buffers busy on the encoder stream
         for (int fb = 0; fb < 2; ++fb) {
