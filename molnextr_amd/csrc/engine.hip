@@ -652,6 +652,7 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
         if (!h->out_trace) {
             HIPCHK(h, hipMalloc((void**)&h->out_trace, (size_t)c.max_len * ROW_TILE * c.vocab * 4));
             h->allocs.push_back(h->out_trace);
+            h->bytes += (size_t)c.max_len * ROW_TILE * c.vocab * 4;
         }
         trace = h->out_trace;
     }
@@ -699,7 +700,7 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
     auto lazy = [&](void** p, size_t bytes) -> hipError_t {
         if (*p) return hipSuccess;
         hipError_t e = hipMalloc(p, bytes);
-        if (e == hipSuccess) h->allocs.push_back(*p);
+        if (e == hipSuccess) { h->allocs.push_back(*p); h->bytes += bytes; }
         return e;
     };
     HIPCHK(h, lazy((void**)&bm.bs, sizeof(BeamState)));
@@ -729,6 +730,10 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
         HIPCHK(h, hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
         hipGraphDestroy(g);
     }
+    struct ExecGuard {      // the per-call graph is released on every exit path
+        hipGraphExec_t& e;
+        ~ExecGuard() { if (e) { hipGraphExecDestroy(e); e = nullptr; } }
+    } guard{exec};
     int rc = MNX_OK;
     const int poll = 8;
     for (int t = 0; t < max_len && rc == MNX_OK;) {
@@ -745,7 +750,6 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
         if (e != hipSuccess) { h->err = std::string("beam poll: ") + hipGetErrorString(e); rc = MNX_ERR_HIP; break; }
         if (*h->host_flag == 0) break;
     }
-    if (exec) hipGraphExecDestroy(exec);
     if (rc != MNX_OK) return rc;
     HIPCHK(h, beam_enqueue_gather(h->db, run, max_len, tokens, lengths, scores, hidden, s));
     HIPCHK(h, hipStreamSynchronize(s));

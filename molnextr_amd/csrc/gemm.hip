@@ -196,7 +196,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-template <typename T, int EPI, int BN>
+// NSTG = 2: double-buffered K loop (64 / 48 KiB LDS, 2-3 workgroups per CU) for the MFMA-bound shapes.
+// NSTG = 1: one stage (34 KiB, 4 workgroups per CU), selectable for small K with MNX_GEMM_1STAGE_K (experiment knob;
+//           not a win overall, see launch_bn).
+template <typename T, int EPI, int BN, int NSTG>
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cout,
                                                            const float* __restrict__ bias, const float* resid, int M,
                                                            int N, int K, int tiles_n, int n_tiles) {
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     constexpr int NT = BN / 32;
     constexpr int WLD = BN / 32;
     constexpr int STG = (BM + BN) * BK * 2;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STG];
+    constexpr int EPI_LDS = 34816;    // largest epilogue staging area: 128 rows x (128 x 2 + 16) B = 128 x (64 x 4 + 16) B
+    __shared__ __attribute__((aligned(16))) char smem[NSTG * STG > EPI_LDS ? NSTG * STG : EPI_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -245,8 +249,8 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* ab = smem + (kt & 1) * STG;
+        if (NSTG == 2 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* ab = smem + (NSTG == 2 ? (kt & 1) * STG : 0);
         const char* wb = ab + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -261,6 +265,10 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
         }
         __syncthreads();   // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer kt&1 for tile kt+2
+        if (NSTG == 1 && kt + 1 < nk) {   // single stage: the buffer is free now, refill it and wait
+            issue(kt + 1, 0);
+            __syncthreads();
+        }
     }
     gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
@@ -271,10 +279,17 @@ static hipError_t launch_bn(int epi, const void* A, const void* W, void* C, cons
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
     const bool glds = (K % BK) == 0 && getenv("MNX_NO_GLDS") == nullptr;
+    // measured at B=64 (tools/gemm_bench.py): one stage helps the bias-only epilogue at K <= 256 by 2-5 % and costs the
+    // GELU epilogue 8-15 % (those launches are bound by the epilogue's VALU + store phase, not by residency): off
+    static const int one_stage_k = getenv("MNX_GEMM_1STAGE_K") ? atoi(getenv("MNX_GEMM_1STAGE_K")) : 0;
+    const bool one = K <= one_stage_k;
 #define MNX_GEMM_CASE(E)                                                                                                  \
     case E:                                                                                                               \
-        if (glds)                                                                                                         \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias,    \
+        if (glds && one)                                                                                                  \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN, 1>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, \
+                               resid, M, N, K, tn, tm * tn);                                                              \
+        else if (glds)                                                                                                    \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN, 2>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, \
                                resid, M, N, K, tn, tm * tn);                                                              \
         else                                                                                                              \
             hipLaunchKernelGGL((gemm_tn_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid,  \
@@ -296,10 +311,13 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
                            int M, int N, int K, hipStream_t s) {
     // tile choice: 128x128 unless its tile count leaves the 512 resident-workgroup slots (256 CUs x 2) badly
     // quantised; then 128x64 tiles (3 workgroups per CU)
+    static const int force_bn = getenv("MNX_GEMM_BN") ? atoi(getenv("MNX_GEMM_BN")) : 0;   // A/B knob (tools)
+    if (force_bn == 64 && N >= 64) return launch_bn<T, 64>(epi, A, W, C, bias, resid, M, N, K, s);
+    if (force_bn == 128) return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const double waves128 = (double)t128 / 512.0;
     const bool small = t128 < 512 || (waves128 < 3.0 && (waves128 - (long)waves128) > 0.0 && (waves128 - (long)waves128) < 0.6);
-    if (small && N >= 64) return launch_bn<T, 64>(epi, A, W, C, bias, resid, M, N, K, s);
+    if ((small || N <= 128) && N >= 64) return launch_bn<T, 64>(epi, A, W, C, bias, resid, M, N, K, s);   // N = 128: +10 %
     return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
 }
 

@@ -48,7 +48,8 @@ def test_native_library_is_loaded(eng):
         assert "libmolnextr_hip.so" in f.read()
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 96, 32), (129, 136, 72), (4608, 1024, 4096), (18432, 2048, 512)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 96, 32), (129, 136, 72), (4608, 1024, 4096), (18432, 2048, 512),
+                                   (1000, 384, 128), (640, 768, 256), (2304, 128, 512), (515, 64, 192)])
 def test_gemm_all_epilogues(eng, dev, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(dev).bfloat16()

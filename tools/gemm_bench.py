@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the encoder MFMA GEMM (mnx_gemm16) on the Swin-B shapes at B=32. MI355X only."""
+"""Micro-benchmark of the encoder MFMA GEMM (mnx_gemm16) on the Swin-B shapes at B=$BATCH (32). MI355X only."""
 import os
 import sys
 import time
@@ -16,12 +16,16 @@ dec = W.DecoderDims(enc_dim=TINY.num_features)
 ck = W.synthetic_checkpoint(0, enc=TINY, dec=dec)
 eng = Engine(ck["encoder"], ck["decoder"], max_batch=2, enc=TINY, dec=dec)
 dev = torch.device("cuda:0")
+SC = int(os.environ.get("BATCH", "32")) // 32          # rows scale with the encoder launch group (BATCH=64: x2)
 shapes = [("qkv s2", 0, 18432, 1536, 512), ("proj s2", 2, 18432, 512, 512), ("fc1 s2", 1, 18432, 2048, 512),
           ("fc2 s2", 2, 18432, 512, 2048), ("qkv s0", 0, 294912, 384, 128), ("fc1 s0", 1, 294912, 512, 128),
-          ("fc2 s0", 2, 294912, 128, 512), ("fc2 s3", 2, 4608, 1024, 4096), ("big", 3, 8192, 8192, 8192)]
+          ("fc2 s0", 2, 294912, 128, 512), ("qkv s1", 0, 73728, 768, 256), ("fc1 s1", 1, 73728, 1024, 256),
+          ("fc2 s1", 2, 73728, 256, 1024), ("qkv s3", 0, 4608, 3072, 1024), ("fc1 s3", 1, 4608, 4096, 1024),
+          ("fc2 s3", 2, 4608, 1024, 4096), ("big", 3, 8192, 8192, 8192)]
 only = sys.argv[1:]
 iters = int(os.environ.get("ITERS", "20"))
 for name, epi, M, N, K in shapes:
+    M = M * SC if name != "big" else M
     if only and name.split()[0] not in only and name not in only:
         continue
     A = torch.randn(M, K, device=dev).bfloat16()
