@@ -18,7 +18,7 @@
 
 namespace mnx {
 
-__device__ int g_ablate = 0;   // experiment knob (tools only): 1 = skip epilogue stores, 2 = skip epilogue math+stores
+__device__ int g_ablate = 0;   // experiment knob (tools only): 1 = skip epilogue stores, 2 = skip the whole epilogue, 4 = skip GELU
 
 constexpr int BM = 128, BK = 64;
 
@@ -73,7 +73,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
                 for (int mt = 0; mt < 4; ++mt) {
                     const int ml = (PASSES == 1 ? wm * 64 : 0) + mt * 16 + fr;
                     f32x4 v = acc[nt][mt] + b4;
-                    if (EPI == EPI_GELU_16) {
+                    if (EPI == EPI_GELU_16 && ablate != 4) {
                         v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
                     }
                     if (OUT16) {
