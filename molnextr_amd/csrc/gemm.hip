@@ -273,6 +273,160 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
 
+// EXPERIMENT (MNX_GEMM_256=1; not the default): measured 1006 TFLOP/s on 8192^3 (883 for the 2-stage 128x128 kernel)
+// and +8 % on the K <= 256 shapes of stage 1/2, but -10 % on Swin-B's dominant K = 512 shapes: one workgroup per CU
+// leaves the prologue and the epilogue of every tile exposed, and 8 K-tiles do not amortise them.
+// 256x128 tile, 8 waves (4 along M x 2 along N, each 64x64 as above), THREE K-tile stages in a ring (144 KiB of LDS,
+// one workgroup per CU) with counted vmcnt: the 2-stage kernels above spend ~1.1 us per K-tile — the global->LDS
+// latency — because only one tile is in flight while a workgroup computes; here two are, and a tile carries twice the
+// MFMA work per byte staged. One barrier per K-tile: wait for the own DMA pieces of tile kt (vmcnt leaves tile kt+1's
+// six pieces outstanding), barrier (every wave's pieces of tile kt have landed, and every wave has finished reading
+// tile kt-1), re-stage tile kt+2 into the buffer of tile kt-1, compute tile kt.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_tn_256_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cout,
+                                                          const float* __restrict__ bias, const float* resid, int M,
+                                                          int N, int K, int tiles_n, int n_tiles) {
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    constexpr int TM = 256, TN_ = 128;
+    constexpr int STG = (TM + TN_) * BK * 2;         // 48 KiB per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 * STG
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN_;
+    const int r_in = lane >> 3, p = lane & 7;
+    const T* a_src[4];
+    const T* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + r_in;
+        a_src[i] = A + (size_t)min(m0 + r, M - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + r_in;
+        w_src[i] = W + (size_t)min(n0 + r, N - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int kt, int stg) {
+        char* ab = smem + stg * STG;
+        char* wb = ab + TM * BK * 2;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + k0), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + k0), (lds_void_t*)(wb + (wave * 2 + i) * 1024), 16, 0, 0);
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = K / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    const int fr = lane & 15, fg = lane >> 4;
+    int cur = 0;                                   // stage of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2, cur == 0 ? 2 : cur - 1);   // (kt + 2) % 3 == (cur + 2) % 3
+        const char* ab = smem + cur * STG;
+        const char* wb = ab + TM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = *(const v8*)(ab + lds_off(wm * 64 + t * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *(const v8*)(wb + lds_off(wn * 64 + t * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();                               // every wave is done with the last stage: LDS becomes the staging area
+    // ---- epilogue: transpose through LDS, whole 128-byte lines out (one pass: the staging area is 144 KiB) ----
+    constexpr bool OUT16 = (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16);
+    constexpr int ELT = OUT16 ? 2 : 4;
+    constexpr int ROWB = TN_ * ELT + 16;
+    constexpr int CH_ROW = TN_ * ELT / 16;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int nl = wn * 64 + nt * 16 + fg * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n0 + nl < N) b4 = *(const f32x4*)(bias + n0 + nl);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int ml = wm * 64 + mt * 16 + fr;
+            f32x4 v = acc[nt][mt] + b4;
+            if (EPI == EPI_GELU_16) {
+                v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
+            }
+            if (OUT16) {
+                v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                *(v4*)(smem + ml * ROWB + nl * 2) = o4;
+            } else {
+                *(f32x4*)(smem + ml * ROWB + nl * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM * CH_ROW / 512; ++i) {
+        const int id = tid + i * 512;
+        const int rl = id / CH_ROW, ch = id % CH_ROW;
+        const int m = m0 + rl;
+        const int n = n0 + ch * (16 / ELT);
+        if (m < M && n < N) {
+            const size_t o = (size_t)m * N + n;
+            if (OUT16) {
+                *(v8*)((T*)Cout + o) = *(const v8*)(smem + rl * ROWB + ch * 16);
+            } else {
+                f32x4 v = *(const f32x4*)(smem + rl * ROWB + ch * 16);
+                if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
+                *(f32x4*)((float*)Cout + o) = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+static hipError_t launch_256(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
+                             int M, int N, int K, hipStream_t s) {
+    constexpr int LDS = 3 * (256 + 128) * BK * 2;
+    const int tm = (M + 255) / 256, tn = (N + 127) / 128;
+    dim3 grid(tm * tn), block(512);
+#define MNX_GEMM256_CASE(E)                                                                                               \
+    case E: {                                                                                                             \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_256_kernel<T, E>,                                     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                          \
+            if (e != hipSuccess) return e;                                                                                \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((gemm_tn_256_kernel<T, E>), grid, block, LDS, s, (const T*)A, (const T*)W, C, bias, resid, M,  \
+                           N, K, tn, tm * tn);                                                                            \
+        break;                                                                                                            \
+    }
+    switch (epi) {
+        MNX_GEMM256_CASE(EPI_BIAS_16)
+        MNX_GEMM256_CASE(EPI_GELU_16)
+        MNX_GEMM256_CASE(EPI_RESID_F32)
+        MNX_GEMM256_CASE(EPI_BIAS_F32)
+        default: return hipErrorInvalidValue;
+    }
+#undef MNX_GEMM256_CASE
+    return hipGetLastError();
+}
+
 template <typename T, int BN>
 static hipError_t launch_bn(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
                             int M, int N, int K, hipStream_t s) {
@@ -311,6 +465,8 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
                            int M, int N, int K, hipStream_t s) {
     // tile choice: 128x128 unless its tile count leaves the 512 resident-workgroup slots (256 CUs x 2) badly
     // quantised; then 128x64 tiles (3 workgroups per CU)
+    static const int use256 = getenv("MNX_GEMM_256") ? atoi(getenv("MNX_GEMM_256")) : 0;   // experiment knob
+    if (use256 && (K % BK) == 0 && K >= 2 * BK && N % 8 == 0) return launch_256<T>(epi, A, W, C, bias, resid, M, N, K, s);
     static const int force_bn = getenv("MNX_GEMM_BN") ? atoi(getenv("MNX_GEMM_BN")) : 0;   // A/B knob (tools)
     if (force_bn == 64 && N >= 64) return launch_bn<T, 64>(epi, A, W, C, bias, resid, M, N, K, s);
     if (force_bn == 128) return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);

@@ -70,6 +70,43 @@ def test_gemm_all_epilogues(eng, dev, M, N, K):
     assert (r2 - (ref + res)).abs().max().item() < 2e-4
 
 
+def test_gemm_256x128_three_stage_variant_in_subprocess():
+    """The 256x128-tile, 3-stage-ring GEMM (MNX_GEMM_256=1, an experiment knob read once per process: 1006 TFLOP/s on
+    8192^3 but slower than the 128x128 kernel on Swin-B's K=512 shapes, so not the default) must stay exact."""
+    import subprocess
+    import sys
+    code = """
+import torch
+from molnextr_amd import weights as W
+from molnextr_amd.engine import Engine
+TINY = W.EncoderDims(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)
+dec = W.DecoderDims(enc_dim=TINY.num_features)
+ck = W.synthetic_checkpoint(0, enc=TINY, dec=dec)
+eng = Engine(ck["encoder"], ck["decoder"], max_batch=2, enc=TINY, dec=dec)
+for (M, N, K) in [(4608, 1024, 4096), (18432, 2048, 512), (1000, 384, 128), (640, 768, 256), (2304, 128, 512), (70000, 256, 256)]:
+    for epi in (0, 1, 2, 3):
+        g = torch.Generator().manual_seed(M + N + K + epi)
+        A = torch.randn(M, K, generator=g).cuda().bfloat16()
+        Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().bfloat16()
+        bias = torch.randn(N, generator=g).cuda()
+        ref = A.float() @ Wt.float().t() + bias
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 2 else torch.bfloat16)
+        if epi == 2:
+            out.normal_(generator=None)
+            ref = ref + out
+        eng.gemm16(epi, A, Wt, out, bias)
+        err = (out.float() - ref).abs().max().item()
+        tol = 2e-4 if epi >= 2 else 3e-2
+        assert err < tol, (M, N, K, epi, err)
+print("ok")
+"""
+    env = dict(os.environ, MNX_GEMM_256="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("dtype,tol", [("bf16", 4e-2), ("fp16", 6e-3)])
 def test_swin_tiny_every_block_vs_reference_golden(golden_dir, dev, dtype, tol):
     gold = np.load(os.path.join(golden_dir, "swin_tiny.npz"))
