@@ -234,7 +234,7 @@ def main():
                     "images_per_launch": eb,
                     "launches": int(launches), "avg_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
                     "flop_per_launch_avg": round(gemm_flop / max(launches, 1))}
-        cpu = None if args.no_cpu_baseline else cpu_baseline(ck)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(ck)   # host baseline: rank 0 at N=1 only
         total = args.steps * BATCH * world
         out = {
             "metric": "molecules/sec (384x384, bs32 per GPU), full predict hot path",
