@@ -69,11 +69,76 @@ __global__ __launch_bounds__(256) void sgemm_tn_kernel(const float* __restrict__
     }
 }
 
+// The same contraction on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains): 64x64 tile, 4 waves of
+// 32x32, operands from global memory straight into the fragment layout (lane (fr, fg): float4 at [row fr][k + 4 fg],
+// the k-slot permutation is the same on both operands), 4 K-chunks of 16 in flight. Used for the per-image work of an
+// admission (enc_transform 4608x256x1024, cross-attention K/V 4608x3072x256). Parity-identical in the GPU tests; end to
+// end it measured within noise of the VALU kernel (the admission work is 1.6 % of the kernel time), so it stays behind
+// MNX_SGEMM_MFMA.
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ C, int M,
+                                                         int N, int K, int perm_S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.y * 64 + (wave & 1) * 32, n0 = blockIdx.x * 64 + (wave >> 1) * 32;
+    const float* ap[2];
+    const float* wp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        ap[t] = A + (size_t)min(m0 + t * 16 + fr, M - 1) * K + fg * 4;
+        wp[t] = W + (size_t)min(n0 + t * 16 + fr, N - 1) * K + fg * 4;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 64) {           // K % 64 == 0
+        f32x4 a[2][4], w[2][4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t][kc] = *(const f32x4*)(ap[t] + k0 + 16 * kc);
+                w[t][kc] = *(const f32x4*)(wp[t] + k0 + 16 * kc);
+            }
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][kc][j], w[0][kc][j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][kc][j], w[1][kc][j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][kc][j], w[0][kc][j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][kc][j], w[1][kc][j], acc[1][1], 0, 0, 0);
+            }
+    }
+    // D layout: lane holds rows fg*4 + r (r = 0..3) of column fr
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + nt * 16 + fr;
+            if (n >= N) continue;
+            const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + mt * 16 + fg * 4 + r;
+                if (m >= M) continue;
+                const size_t off = perm_S > 0 ? ((((size_t)(m / perm_S) * (N >> 8) + (n >> 8)) * 8 + ((n & 255) >> 5)) * perm_S +
+                                                 (m % perm_S)) * 32 + (n & 31)
+                                              : (size_t)m * N + n;
+                C[off] = acc[mt][nt][r] + b;
+            }
+        }
+}
+
 hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                            hipStream_t s, int perm_S) {
     if ((K & 15) || (N & 3) || (perm_S > 0 && ((N & 255) || M % perm_S))) return hipErrorInvalidValue;
+    static const bool valu = getenv("MNX_SGEMM_MFMA") == nullptr;     // A/B knob: MFMA form (parity-identical, no end-to-end gain)
     dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-    hipLaunchKernelGGL(sgemm_tn_kernel, grid, block, 0, s, A, W, bias, C, M, N, K, perm_S);
+    if (!valu && (K & 63) == 0 && M >= 1024)
+        hipLaunchKernelGGL(sgemm_mfma_kernel, grid, block, 0, s, A, W, bias, C, M, N, K, perm_S);
+    else
+        hipLaunchKernelGGL(sgemm_tn_kernel, grid, block, 0, s, A, W, bias, C, M, N, K, perm_S);
     return hipGetLastError();
 }
 
