@@ -390,6 +390,16 @@ def test_grouped_encode_gives_identical_predictions(eng, dev, synth_ckpt):
     _same_predictions(c, eng.predict(imgs[:40].contiguous(), ref_batch=32))
 
 
+def test_predict_results_do_not_depend_on_neighbouring_work(eng, dev):
+    """Continuous batching keeps sequences of many reference batches in one set of slots; a batch's results must not
+    depend on what else is resident (slot tiles, tick sizes, admission order): the last batch of a 96-image job equals
+    the same 32 images decoded alone."""
+    imgs = W.synthetic_images(96, first_index=300).to(dev)
+    whole = eng.predict(imgs, ref_batch=32)
+    alone = eng.predict(imgs[64:].contiguous(), ref_batch=32)
+    _same_predictions({k: v[64:] for k, v in whole.items()}, alone)
+
+
 def test_device_atom_scan_vs_reference_golden_and_fuzz(golden_dir, eng, dev):
     """The on-device restatement of sequence_to_smiles' 'indices': reference golden cases + a fuzz against the host
     tokenizer (itself pinned by the same golden cases)."""
