@@ -189,9 +189,10 @@ int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C
                int32_t N, int32_t K, void* stream);
 
 /* Measurement aid for bench.py: while enabled, mnx_encode brackets every MFMA GEMM launch with a pair of HIP
- * events recorded on the caller's stream. mnx_profile_read synchronises, returns the totals accumulated since
- * the last read (summed event-to-event milliseconds, algorithmic FLOP = 2*M*N*K per launch, launch count) and
- * resets them. */
+ * events recorded on the stream the kernel is launched on (also inside mnx_predict, i.e. live in a timed region).
+ * `enable` = n > 0: every n-th mnx_encode call since the enable is bracketed, at most 16 calls (the event pool stays
+ * small and is reused). mnx_profile_read synchronises, returns the totals accumulated since the last read (summed
+ * event-to-event milliseconds, algorithmic FLOP = 2*M*N*K per launch, launch count) and resets them. */
 int mnx_profile_enable(mnx_engine* h, int32_t enable);
 int mnx_profile_read(mnx_engine* h, double* gemm_ms, double* gemm_flop, int64_t* gemm_launches);
 

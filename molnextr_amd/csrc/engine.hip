@@ -77,6 +77,9 @@ struct mnx_engine {
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
     // profiling (bench aid)
     bool profiling = false;
+    int prof_stride = 1;       // bracket the GEMMs of every prof_stride-th mnx_encode call ...
+    int prof_calls = 0;        // ... counted since mnx_profile_enable
+    int prof_groups = 0;       // encode calls bracketed so far (capped: the event pool stays small)
     struct Ev { hipEvent_t a, b; double flop; };
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
@@ -547,9 +550,12 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         ++item;
         return e;
     };
+    // sampled measurement: every prof_stride-th encode call, at most 16 calls per enable
+    const bool bracket = h->profiling && (h->prof_calls++ % h->prof_stride) == 0 && h->prof_groups < 16;
+    if (bracket) ++h->prof_groups;
     auto gemm = [&](int epi, const void* A, const void* Wt, void* Cc, const float* bias, const float* resid, int M,
                     int N, int K) -> hipError_t {
-        if (!h->profiling) return launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s);
+        if (!bracket) return launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s);
         if (h->ev_used == h->ev_pool.size()) {
             mnx_engine::Ev ev{};
             hipError_t e1 = hipEventCreate(&ev.a), e2 = hipEventCreate(&ev.b);
@@ -974,6 +980,9 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
 int mnx_profile_enable(mnx_engine* h, int32_t enable) {
     if (!h) return MNX_ERR_INVALID_ARG;
     h->profiling = enable != 0;
+    h->prof_stride = enable > 1 ? enable : 1;
+    h->prof_calls = 0;
+    h->prof_groups = 0;
     return MNX_OK;
 }
 

@@ -300,7 +300,8 @@ class Engine:
                                            _stream()), "mnx_atom_scan")
         return idx, cnt
 
-    def profile(self, enable: bool):
+    def profile(self, enable):
+        """True / n: bracket the GEMMs of every n-th encode call with HIP events (at most 16 calls); False: off."""
         self._check(self.lib.mnx_profile_enable(self.h, int(enable)), "mnx_profile_enable")
 
     def profile_read(self):
