@@ -59,3 +59,18 @@ def test_engine_refuses_to_run_without_gpu():
     ck = W.synthetic_checkpoint(0, enc=tiny, dec=dec)
     with pytest.raises(engine.MnxError, match="no CPU fallback"):
         engine.Engine(ck["encoder"], ck["decoder"], enc=tiny, dec=dec)
+
+
+def test_header_and_c_example_are_plain_c99(tmp_path):
+    """The boundary is a C ABI: the public header and the C usage example must compile with a bare C compiler."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "examples", "predict_c_abi.c")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                        "-c", src, "-o", str(tmp_path / "ex.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
