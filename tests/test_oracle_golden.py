@@ -146,3 +146,29 @@ def test_beam_strategy_vs_reference_class(golden_dir, case):
         for r in range(NB):
             assert st.results[b][r][1] == g[f"{case}_pred{b}_{r}"].tolist(), f"image {b} rank {r}"
             assert st.results[b][r][0] == pytest.approx(float(g[f"{case}_final{b}_{r}"][0]), abs=0)
+
+
+def test_beam_decode_with_one_beam_equals_greedy(synth_ckpt):
+    """The loop around the (pinned) beam strategy is ours; with beam = n_best = 1 it must collapse to the greedy search
+    that IS pinned on the reference (same ids, same decoder outputs, score = sum(logp) / (tokens + 1))."""
+    from oracle.beam import beam_decode
+    feats = W.hash_normal("beam_eq_greedy", (3, 144, 1024), 0.5)
+    g = greedy_decode(feats, synth_ckpt["decoder"], max_len=48)
+    b = beam_decode(feats, synth_ckpt["decoder"], beam=1, n_best=1, max_len=48)
+    for i in range(3):
+        assert b.tokens[i][0] == g.tokens[i]
+        assert torch.allclose(b.hidden[i][0], g.hidden[i], atol=1e-5)
+        assert b.scores[i][0] == pytest.approx(sum(g.token_logp[i]) / (len(g.tokens[i]) + 1), rel=1e-5)
+
+
+def test_beam_decode_hypotheses_are_ordered_and_grammatical(synth_ckpt):
+    from oracle.beam import beam_decode
+    feats = W.hash_normal("beam_props", (2, 144, 1024), 0.5)
+    b = beam_decode(feats, synth_ckpt["decoder"], beam=4, n_best=3, max_len=40)
+    for i in range(2):
+        assert len(b.tokens[i]) == 3 and b.scores[i] == sorted(b.scores[i], reverse=True)
+        for seq in b.tokens[i]:
+            seq = np.array(seq)
+            assert (seq[:-1] != 2).all()                                   # EOS only as the last id
+            prev_x = (seq[:-1] >= 101) & (seq[:-1] < 165)
+            assert (seq[1:][prev_x] >= 165).all()                          # grammar mask holds inside the beam
