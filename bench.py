@@ -194,18 +194,21 @@ def main():
     # pinned landing buffer for the result records, allocated once outside the timed region (capacity: every record
     # at the engine's max_atoms; the records actually exchanged are sized by the largest molecule of the job)
     gathered = world if (rank == 0 and (world > 1 or args.force_gather)) else 1
+    if args.steps < 1:
+        raise SystemExit("--steps must be >= 1")
     host_buf["pinned"] = torch.empty(max(args.steps, args.warmup) * BATCH * gathered * shard.record_words(kmax),
                                      dtype=torch.int32, pin_memory=True)
     eb = max(BATCH, args.encode_batch)   # images per encoder launch group
     live = args.mode == "pipeline"
     groups = max(1, args.steps * BATCH // eb)
     stride = max(1, groups // 12)        # ~12 encoder launch groups of the timed region get their GEMMs bracketed
-    imgs = run(0, args.warmup)
-    if live:
-        eng.profile(max(1, args.warmup * BATCH // eb // 12))    # creates the event pool outside the timed region
-    process(imgs, args.warmup)
-    if live:
-        eng.profile_read()
+    if args.warmup > 0:
+        imgs = run(0, args.warmup)
+        if live:
+            eng.profile(max(1, args.warmup * BATCH // eb // 12))    # creates the event pool outside the timed region
+        process(imgs, args.warmup)
+        if live:
+            eng.profile_read()
     imgs = run(args.warmup, args.steps)
     if live:
         eng.profile(stride)              # HIP events on the encoder stream, live inside the timed region
