@@ -10,7 +10,8 @@
  * pointers and sizes (no torch / C++ types), return 0 on success or a negative mnx_status, never throw, and
  * enqueue their GPU work on the caller's HIP stream. Device pointers are raw HBM addresses (e.g. a PyTorch-ROCm
  * tensor's data_ptr()). A handle is bound to one device and is not re-entrant: one in-flight call per handle;
- * different handles (GPUs) may be driven from different threads or processes. There is no global mutable state.
+ * different handles (GPUs) may be driven from different threads or processes. The only process-wide state is the
+ * message of the last failed mnx_create (read it with mnx_last_error(NULL) from the thread that called mnx_create).
  */
 #ifndef MOLNEXTR_HIP_H
 #define MOLNEXTR_HIP_H
@@ -22,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MNX_ABI_VERSION 2
+#define MNX_ABI_VERSION 3
 
 typedef struct mnx_engine mnx_engine;
 
@@ -35,7 +36,11 @@ typedef enum {
     MNX_ERR_CAPACITY = -5       /* batch / length / atom count exceeds what mnx_create reserved   */
 } mnx_status;
 
-enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1 };   /* operand type of the encoder MFMA GEMMs */
+/* Operand type of the encoder MFMA GEMMs / window attention (accumulation, residual stream, LayerNorm and softmax are
+ * fp32 in every mode; the decoder and the bond head are fp32 always). FP32 is the parity mode: every encoder operand in
+ * fp32 on the exact-fp32 matrix instructions (1/16 of the bf16 rate) — tokens / atoms / bonds equal the reference from
+ * pixels; BF16 is the throughput mode north_star asks for (near-tie argmax decisions can differ). */
+enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1, MNX_DTYPE_FP32 = 2 };
 
 /* Architecture + capacity. Defaults of the reference inference config are in the comments
  * (MolNexTR/models/transformers.py:547-551 swin_base; MolNexTR/model.py:50-81; MolNexTR/utils.py:25). */
@@ -145,15 +150,21 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
 int mnx_edges(mnx_engine* h, const float* hidden, const int32_t* atom_idx, const int32_t* n_atoms, int32_t B,
               int32_t kmax, int32_t max_len, uint8_t* edges, double* scores, void* stream);
 
-/* The transform in front of the encoder (MolNexTR/dataset.py:158-185 with augment=False; data_aug.py:98-143;
- * applied per image at model.py:104): CropWhite(pad) -> Resize(img_size, bilinear) -> ToGray -> Normalize -> CHW.
+/* The transform in front of the encoder (MolNexTR/dataset.py:158-185 with augment=False; data_aug.py:98-143,286-301;
+ * applied per image at model.py:104): CropWhite(pad) [-> PadToSquare] -> Resize(img_size, bilinear) -> ToGray ->
+ * Normalize -> CHW.
  *   rgb      device uint8 [height,width,3] (RGB, as cv2.cvtColor(BGR2RGB) leaves it)
  *   pad      white border added around the ink bounding box (the reference uses 50)
+ *   pad_to_square  1 = insert PadToSquare after CropWhite, as `get_transforms` does for test files 'real/acs.csv' and
+ *            'real/UOB.csv' (dataset.py:163-164): the shorter side is padded white, diff//2 before, the rest after
+ *   crop_out device int32 [4] or NULL: {crop_top, crop_bottom, crop_left, crop_right} exactly as
+ *            CropWhite.update_params computes them (data_aug.py:106-136) — pinned by tests/golden/crop_pad.json
  *   out      device fp32 [3,img_size,img_size] — one image of mnx_encode's input
- * Asynchronous on `stream`. Bit-identical to molnextr_amd/preprocess.py (the host restatement of the
- * albumentations/OpenCV arithmetic; unpinned against the reference). */
-int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t width, int32_t pad, float* out,
-                   void* stream);
+ * Asynchronous on `stream`. Bit-identical to molnextr_amd/preprocess.py. CropWhite / PadToSquare are pinned on the
+ * reference's own classes (golden crop boxes, shapes, content hashes); the OpenCV resize / gray arithmetic is restated
+ * from its documented behaviour and unpinned (OpenCV is not installable here), see DESIGN.md. */
+int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t width, int32_t pad,
+                   int32_t pad_to_square, int32_t* crop_out, float* out, void* stream);
 
 /* Token classes for the on-device atom-position scan used by mnx_predict (the 'indices' that
  * CharTokenizer.sequence_to_smiles derives, MolNexTR/tokenization.py:464-515). flags[id]: bit0 = is_symbol(id),
@@ -172,8 +183,8 @@ int mnx_atom_scan(mnx_engine* h, const int32_t* tokens, const int32_t* lengths, 
  *   images    device fp32 [n_img,3,S,S]
  *   ref_batch images are decoded as consecutive reference batches of this many rows (<= 32): every batch is one
  *             positional-encoding numbering, exactly as if the reference had been called with this batch_size
- * Up to 256 sequences (8 reference batches) are resident on the GPU at once; every decode tick advances all of
- * them by one token, finished batches are retired (atom positions + bond head run on device) and the freed rows are
+ * Up to cfg.dec_slots sequences (dec_slots / 32 reference batches; 2048 by default) are resident on the GPU at once;
+ * every decode tick advances all of them by one token, finished batches are retired (atom positions + bond head run on device) and the freed rows are
  * refilled with the next batch while the encoder of the following batch runs on a second stream.
  *   tokens    device int32 [n_img,max_len]; lengths device int32 [n_img]
  *   n_atoms   device int32 [n_img]; atom_idx device int32 [n_img,kmax]; edges device uint8 [n_img,kmax,kmax]

@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 
 #define MNX_WAVE 64
 
@@ -28,6 +29,19 @@ template <> struct H16<f16_t> {
     typedef f16x4 v4;
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// fp32 "parity mode" (compute_dtype FP32): the same kernels instantiated on float operands. The 16x16x32 contraction is
+// eight exact-fp32 v_mfma_f32_16x16x4_f32 steps: lane (fr, fg) holds k = 8 fg + i (i = 0..7) of its row on BOTH operands,
+// step i feeds element i as k-slot fg, so the four lane groups cover k = i, 8+i, 16+i, 24+i — every k exactly once.
+template <> struct H16<float> {
+    typedef f32x8 v8;
+    typedef f32x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], c, 0, 0, 0);
+        return c;
     }
 };
 

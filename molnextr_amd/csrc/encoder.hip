@@ -170,6 +170,8 @@ hipError_t launch_layernorm16(int dtype, const float* x, const float* gamma, con
     dim3 grid((M + 3) / 4);
     if (dtype == MNX_DT_F16)
         ln_dispatch<f16_t, false>(grid, s, x, gamma, beta, (f16_t*)y16, y32, M, C, eps, 0, 0, 0);
+    else if (dtype == MNX_DT_F32)
+        ln_dispatch<float, false>(grid, s, x, gamma, beta, (float*)y16, y32, M, C, eps, 0, 0, 0);
     else
         ln_dispatch<bf16_t, false>(grid, s, x, gamma, beta, (bf16_t*)y16, y32, M, C, eps, 0, 0, 0);
     return hipGetLastError();
@@ -182,6 +184,8 @@ hipError_t launch_merge_ln16(int dtype, const float* x, const float* gamma, cons
     dim3 grid((M + 3) / 4);
     if (dtype == MNX_DT_F16)
         ln_dispatch<f16_t, true>(grid, s, x, gamma, beta, (f16_t*)y16, nullptr, M, 4 * C, eps, H, W, C);
+    else if (dtype == MNX_DT_F32)
+        ln_dispatch<float, true>(grid, s, x, gamma, beta, (float*)y16, nullptr, M, 4 * C, eps, H, W, C);
     else
         ln_dispatch<bf16_t, true>(grid, s, x, gamma, beta, (bf16_t*)y16, nullptr, M, 4 * C, eps, H, W, C);
     return hipGetLastError();
@@ -203,6 +207,8 @@ hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStre
     dim3 grid((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)), block(256);
     if (dtype == MNX_DT_F16)
         hipLaunchKernelGGL((cast16_kernel<f16_t>), grid, block, 0, s, x, (f16_t*)y16, n4);
+    else if (dtype == MNX_DT_F32)
+        hipLaunchKernelGGL((cast16_kernel<float>), grid, block, 0, s, x, (float*)y16, n4);
     else
         hipLaunchKernelGGL((cast16_kernel<bf16_t>), grid, block, 0, s, x, (bf16_t*)y16, n4);
     return hipGetLastError();
@@ -212,7 +218,7 @@ hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStre
 // K4  (shifted-)window attention, window 12x12 = 144 tokens, head_dim 32
 //     (reference transformers.py:68-97 partition/reverse, :147-178 attention, :220-243 shift mask, :260-282 roll)
 //
-//     One workgroup (3 waves) per (image, window, head). The cyclic shift, the window partition and their
+//     One workgroup (9 waves, one 16-query tile each) per (image, window, head). The cyclic shift, the window partition and their
 //     inverses are index arithmetic on the token row — nothing is materialised: the kernel reads q,k,v of
 //     the 144 window tokens straight from the [B*L, 3C] qkv buffer and writes the head's 32 output channels
 //     back at the tokens' ORIGINAL rows. Scores live in MFMA accumulators only.
@@ -226,11 +232,11 @@ constexpr int WS = 12, WN = 144, HD = 32;
 constexpr int KS_STRIDE = 40;    // elements per K row in LDS (80 B: conflict-free ds_read_b128)
 constexpr int VT_STRIDE = 168;   // elements per V^T row in LDS (336 B: conflict-free ds_read_b64), keys 144..167 zero
 
-template <typename T, int QT>   // QT query tiles (of 16) per wave; 9 / QT waves per workgroup
-__global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __restrict__ qkv,
+template <typename T>
+__global__ __launch_bounds__(576) void window_attn_kernel(const T* __restrict__ qkv,
                                                                   const float* __restrict__ table, T* __restrict__ out,
-                                                                  int H, int W, int C, int heads, int shift, int xcd) {
-    constexpr int NTHR = 64 * 9 / QT;
+                                                                  int H, int W, int C, int heads, int shift) {
+    constexpr int QT = 1, NTHR = 576;   // 9 waves, one 16-query tile each
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
     __shared__ __attribute__((aligned(16))) T Ks[WN * KS_STRIDE];
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __res
     const int nWw = W / WS, nWh = H / WS;
     // XCD-aware: the heads of one window are consecutive ids, and consecutive ids share an XCD (= an L2), so the two
     // heads that share every 128-byte line of q / k / v / out hit the same L2 instead of fetching the line twice
-    int bid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int head = bid % heads; bid /= heads;
     const int wx = bid % nWw; bid /= nWw;
     const int wy = bid % nWh;
@@ -367,14 +373,13 @@ __global__ __launch_bounds__(64 * 9 / QT) void window_attn_kernel(const T* __res
 hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,
                               int C, int heads, int shift, hipStream_t s) {
     if (C != heads * HD || H % WS || W % WS) return hipErrorInvalidValue;
-    static const int qt = getenv("MNX_ATTN_QT") ? atoi(getenv("MNX_ATTN_QT")) : 1;
-    static const int xcd = getenv("MNX_ATTN_NO_XCD") ? 0 : 1;
     dim3 grid(B * (H / WS) * (W / WS) * heads);
-#define MNX_ATTN(TT, Q)                                                                                              \
-    hipLaunchKernelGGL((window_attn_kernel<TT, Q>), grid, dim3(64 * 9 / Q), 0, s, (const TT*)qkv16, rel_table,      \
-                       (TT*)out16, H, W, C, heads, shift, xcd)
-    if (dtype == MNX_DT_F16) { if (qt == 3) MNX_ATTN(f16_t, 3); else MNX_ATTN(f16_t, 1); }
-    else { if (qt == 3) MNX_ATTN(bf16_t, 3); else MNX_ATTN(bf16_t, 1); }
+#define MNX_ATTN(TT)                                                                                                  \
+    hipLaunchKernelGGL((window_attn_kernel<TT>), grid, dim3(576), 0, s, (const TT*)qkv16, rel_table, (TT*)out16, H, W, \
+                       C, heads, shift)
+    if (dtype == MNX_DT_F16) MNX_ATTN(f16_t);
+    else if (dtype == MNX_DT_F32) MNX_ATTN(float);
+    else MNX_ATTN(bf16_t);
 #undef MNX_ATTN
     return hipGetLastError();
 }

@@ -19,11 +19,9 @@
 
 using namespace mnx;
 
-namespace mnx { void set_gemm_ablate(int v); }
-
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;   // message of the calling thread's last failed mnx_create
 
 struct BlockW {
     float *ln1_g, *ln1_b, *table, *qkv_b, *proj_b, *ln2_g, *ln2_b, *fc1_b, *fc2_b;
@@ -65,7 +63,6 @@ struct mnx_engine {
     std::map<GraphKey, hipGraphExec_t> graphs;
     // continuous-batching pipeline (mnx_predict)
     hipStream_t enc_stream = nullptr;
-    hipStream_t dec_stream = nullptr;   // CU-masked decode stream (MNX_DEC_CUS > 0), else the caller's stream is used
     hipEvent_t ev_order = nullptr;
     float* feat_ring[2] = {nullptr, nullptr};
     hipEvent_t ev_enc_done[2] = {nullptr, nullptr}, ev_feat_free[2] = {nullptr, nullptr}, ev_poll[2] = {nullptr, nullptr};
@@ -153,7 +150,7 @@ struct Packer {
             problems.push_back("staging too small for " + name);
             return nullptr;
         }
-        void* p = dalloc(n * 2);
+        void* p = dalloc(n * dt_size(h->cfg.compute_dtype));
         if (!p) return nullptr;
         if (hipMemcpy(staging, d->data, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
             launch_cast16(h->cfg.compute_dtype, staging, p, n, 0) != hipSuccess ||
@@ -192,7 +189,8 @@ int check_cfg(const mnx_config& c, std::string& why) {
     if (c.max_len < 1 || c.max_len > 512) return bad("max_len must be 1..512");
     if (c.max_batch < 1) return bad("max_batch < 1");
     if (c.max_atoms < 1 || c.max_atoms > 256) return bad("max_atoms must be 1..256");
-    if (c.compute_dtype != MNX_DTYPE_BF16 && c.compute_dtype != MNX_DTYPE_FP16) return bad("compute_dtype");
+    if (c.compute_dtype != MNX_DTYPE_BF16 && c.compute_dtype != MNX_DTYPE_FP16 && c.compute_dtype != MNX_DTYPE_FP32)
+        return bad("compute_dtype");
     if (c.dec_slots < 0 || c.dec_slots > MAX_SLOTS || (c.dec_slots % ROW_TILE) != 0) return bad("dec_slots");
     if (c.pe_len < ROW_TILE) return bad("pe_len too small");
     return MNX_OK;
@@ -214,7 +212,6 @@ void mnx_destroy(mnx_engine* h) {
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     if (h->enc_stream) hipStreamDestroy(h->enc_stream);
-    if (h->dec_stream) hipStreamDestroy(h->dec_stream);
     if (h->ev_order) hipEventDestroy(h->ev_order);
     for (int i = 0; i < 2; ++i) {
         if (h->ev_enc_done[i]) hipEventDestroy(h->ev_enc_done[i]);
@@ -447,10 +444,11 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     }
     h->xa = (float*)P.dalloc(MB * L0 * C0 * 4);
     h->xb = (float*)P.dalloc(MB * L0 * C0 * 4 / 2);
-    h->xn16 = P.dalloc(MB * max_xn * 2);
-    h->qkv16 = P.dalloc(MB * max_qkv * 2);
-    h->attn16 = P.dalloc(MB * max_xn * 2);
-    h->h16 = P.dalloc(MB * max_h * 2);
+    const size_t es = dt_size(c.compute_dtype);     // operand element size: 2 (bf16 / fp16) or 4 (fp32 parity mode)
+    h->xn16 = P.dalloc(MB * max_xn * es);
+    h->qkv16 = P.dalloc(MB * max_qkv * es);
+    h->attn16 = P.dalloc(MB * max_xn * es);
+    h->h16 = P.dalloc(MB * max_h * es);
     DecBuffers& db = h->db;
     const int SL = c.dec_slots > 0 ? c.dec_slots : 2048;
     h->n_chunk_bufs = SL / ROW_TILE;   // one reference batch per 32-slot row tile
@@ -478,26 +476,12 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->slot_lists = (int*)P.dalloc((size_t)MAX_CHUNKS * ROW_TILE * 4);
     h->tc_dev = (TokenClasses*)P.dalloc(sizeof(TokenClasses));
     {
-        // Encoder and decoder run concurrently on separate streams. With MNX_DEC_CUS=n (default 0 = off) the chip is
-        // partitioned: the decode ticks (chains of ~50 tiny dependent kernels) get n CUs of their own and the
-        // encoder's large GEMM grids the rest, so neither queues behind the other's workgroups.
-        const char* dc = getenv("MNX_DEC_CUS");
-        const int dec_cus = dc ? atoi(dc) : 0;   // measured: 0 (no partition) 1976 mol/s, 96 CUs 1575, 64 CUs 1222, 32 CUs 693
-        const int total = prop.multiProcessorCount;
-        if (dec_cus > 0 && dec_cus < total && total <= 512) {
-            uint32_t mdec[16] = {0}, menc[16] = {0};
-            for (int i = 0; i < total; ++i) ((i < dec_cus) ? mdec : menc)[i >> 5] |= 1u << (i & 31);
-            const uint32_t words = (uint32_t)((total + 31) / 32);
-            if (hipExtStreamCreateWithCUMask(&h->dec_stream, words, mdec) != hipSuccess ||
-                hipExtStreamCreateWithCUMask(&h->enc_stream, words, menc) != hipSuccess)
-                P.problems.push_back("CU-masked stream create failed");
-        } else {
-            int lo = 0, hi = 0;   // no partition: stream priority instead (lo = numerically greatest = least urgent)
-            hipDeviceGetStreamPriorityRange(&lo, &hi);
-            const char* ep = getenv("MNX_ENC_PRIO");
-            const int prio = (ep && ep[0] == 'l') ? lo : ((ep && ep[0] == 'n') ? (lo + hi) / 2 : hi);   // measured: high 2516, normal 2500, low 2477 mol/s
-            if (hipStreamCreateWithPriority(&h->enc_stream, hipStreamNonBlocking, prio) != hipSuccess) P.problems.push_back("stream create failed");
-        }
+        // Encoder and decoder run concurrently on separate streams; the encoder stream gets the high priority (its
+        // large GEMM grids otherwise queue behind the decode ticks' many small kernels: measured +1.6 %). Partitioning
+        // the chip with CU masks instead was measured and rejected.
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->enc_stream, hipStreamNonBlocking, hi) != hipSuccess) P.problems.push_back("stream create failed");
         if (hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) != hipSuccess) P.problems.push_back("event create failed");
     }
     for (int i = 0; i < 2; ++i)
@@ -762,8 +746,8 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
     return MNX_OK;
 }
 
-int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t width, int32_t pad, float* out,
-                   void* stream) {
+int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t width, int32_t pad,
+                   int32_t pad_to_square, int32_t* crop_out, float* out, void* stream) {
     if (!h) return MNX_ERR_INVALID_ARG;
     if (!rgb || !out || height < 1 || width < 1 || pad < 0) { h->err = "mnx_preprocess: null/empty argument"; return MNX_ERR_INVALID_ARG; }
     if (height > 16384 || width > 16384 || pad > 4096) { h->err = "mnx_preprocess: image larger than 16384x16384"; return MNX_ERR_CAPACITY; }
@@ -772,7 +756,8 @@ int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t wi
         HIPCHK(h, hipMalloc((void**)&h->prep_bbox, 4 * sizeof(int)));
         h->allocs.push_back(h->prep_bbox);
     }
-    HIPCHK(h, launch_preprocess(rgb, height, width, pad, h->cfg.img_size, h->prep_bbox, out, (hipStream_t)stream));
+    HIPCHK(h, launch_preprocess(rgb, height, width, pad, pad_to_square ? 1 : 0, h->cfg.img_size, h->prep_bbox, crop_out, out,
+                                (hipStream_t)stream));
     return MNX_OK;
 }
 
@@ -833,11 +818,6 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         if (!h->own_stream) HIPCHK(h, hipStreamCreate(&h->own_stream));
         s = h->own_stream;
     }
-    if (h->dec_stream) {      // run the whole pipeline on the CU-masked decode stream, ordered after the caller's stream
-        HIPCHK(h, hipEventRecord(h->ev_order, s));
-        HIPCHK(h, hipStreamWaitEvent(h->dec_stream, h->ev_order, 0));
-        s = h->dec_stream;
-    }
     const int S = h->db.S, D = c.dec_dim, SL = h->db.slots;
     const size_t img_elems = (size_t)3 * c.img_size * c.img_size;
     const int n_chunks = (n_img + ref_batch - 1) / ref_batch;
@@ -857,17 +837,24 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     int next = 0, done = 0, seq = 0;
     const char* trace_path = getenv("MNX_TRACE");
     FILE* tf = trace_path ? fopen(trace_path, "a") : nullptr;
+    struct ExitGuard {      // every exit path: nothing of this call may still be in flight, the trace file is closed
+        mnx_engine* h; hipStream_t s; FILE*& tf;
+        ~ExitGuard() {
+            (void)hipStreamSynchronize(h->enc_stream);
+            (void)hipStreamSynchronize(s);
+            if (tf) { fclose(tf); tf = nullptr; }
+        }
+    } exit_guard{h, s, tf};
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_begin = now_ms();
     double host_wait_ms = 0.0;
-    static const int target_rows = getenv("MNX_TARGET_ROWS") ? atoi(getenv("MNX_TARGET_ROWS")) : 0;
     int next_enc = 0;                       // next chunk to hand to the encoder stream
     // the encoder is batch-invariant, so it runs on GROUPS of reference batches (as many as max_batch holds):
     // bigger GEMM grids, half the launches; each reference batch of the group is admitted on its own
     const int grp = std::max(1, c.max_batch / ref_batch);
     int fb_first[2] = {-1, -1}, fb_count[2] = {0, 0};   // chunks [first, first+count) live in feature buffer i
     bool feat_used[2] = {false, false};
-    static const int ticks_per_poll = getenv("MNX_TICKS_PER_POLL") ? std::max(1, atoi(getenv("MNX_TICKS_PER_POLL"))) : 4;
+    const int ticks_per_poll = 4;            // measured: 2-4 equal, 8 = -4 % (retirement lags)
     while (done < n_chunks) {
         // ---- encoder prefetch: keep both feature buffers busy on the encoder stream
         for (int fb = 0; fb < 2; ++fb) {
@@ -890,9 +877,8 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
                 if (fb_first[i] >= 0 && next >= fb_first[i] && next < fb_first[i] + fb_count[i]) fb = i;
             if (fb < 0) break;
             const int first = next * ref_batch, n = std::min(ref_batch, n_img - first);
-            // nothing to decode, or fewer alive rows than the target tick size while the encoder still has work:
-            // wait for the features instead of ticking (bigger ticks amortise the tick's fixed launch cost)
-            const bool idle = live.empty() || (target_rows > 0 && bound < target_rows);
+            // nothing to decode: wait for the features instead of polling
+            const bool idle = live.empty();
             hipError_t q = idle ? hipEventSynchronize(h->ev_enc_done[fb]) : hipEventQuery(h->ev_enc_done[fb]);
             if (q == hipErrorNotReady) break;
             if (q != hipSuccess) { h->err = std::string("encoder event: ") + hipGetErrorString(q); return MNX_ERR_HIP; }
@@ -973,7 +959,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         if (seq > 200000) { h->err = "mnx_predict: watchdog (decode did not terminate)"; return MNX_ERR_HIP; }
     }
     HIPCHK(h, hipStreamSynchronize(s));
-    if (tf) { fprintf(tf, "%.3f end host_wait_ms %.3f\n", now_ms() - t_begin, host_wait_ms); fclose(tf); }
+    if (tf) fprintf(tf, "%.3f end host_wait_ms %.3f\n", now_ms() - t_begin, host_wait_ms);
     return MNX_OK;
 }
 
@@ -1008,7 +994,6 @@ int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C
                int32_t N, int32_t K, void* stream) {
     if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    { static int last = -1; const char* ab = getenv("MNX_ABLATE"); int v = ab ? atoi(ab) : 0; if (v != last) { mnx::set_gemm_ablate(v); last = v; } }
     HIPCHK(h, launch_gemm16(h->cfg.compute_dtype, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
                             M, N, K, (hipStream_t)stream));
     return MNX_OK;

@@ -11,14 +11,10 @@
 // global loads in flight under the MFMAs. The MFMA is issued "swapped" (A-operand = W rows, B-operand =
 // activation rows) so each lane ends up holding 4 CONSECUTIVE output columns of one row: the epilogue stores
 // 8-byte (16-bit out) or 16-byte (fp32 out) vectors and reads bias/residual as float4.
-#include <stdlib.h>
-
 #include "common.h"
 #include "kernels.h"
 
 namespace mnx {
-
-__device__ int g_ablate = 0;   // experiment knob (tools only): 1 = skip epilogue stores, 2 = skip the whole epilogue, 4 = skip GELU
 
 constexpr int BM = 128, BK = 64;
 
@@ -48,16 +44,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
     constexpr int ROWB = BN * ELT + 16;                  // padded LDS row (bytes)
     constexpr int CH_ROW = BN * ELT / 16;                // 16-byte chunks per output row
     const int tid = threadIdx.x;
-    const int ablate = g_ablate;
-    if (ablate == 2) {
-        float s = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) s += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
-        if (s == 12345.678f) ((float*)Cout)[0] = s;
-        return;
-    }
     // fp32 tiles of 128x128 do not fit the staging area at once: two passes of 64 rows (one per wave row wm)
     constexpr int PASSES = (!OUT16 && BN == 128) ? 2 : 1;
     constexpr int ROWS = BM / PASSES;
@@ -73,7 +59,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
                 for (int mt = 0; mt < 4; ++mt) {
                     const int ml = (PASSES == 1 ? wm * 64 : 0) + mt * 16 + fr;
                     f32x4 v = acc[nt][mt] + b4;
-                    if (EPI == EPI_GELU_16 && ablate != 4) {
+                    if (EPI == EPI_GELU_16) {
                         v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
                     }
                     if (OUT16) {
@@ -96,11 +82,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
                 const size_t o = (size_t)m * N + n;
                 if (OUT16) {
                     const v8 v = *(const v8*)(smem + rl * ROWB + ch * 16);
-                    if (ablate != 1) *(v8*)((T*)Cout + o) = v;
+                    *(v8*)((T*)Cout + o) = v;
                 } else {
                     f32x4 v = *(const f32x4*)(smem + rl * ROWB + ch * 16);
                     if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
-                    if (ablate != 1) *(f32x4*)((float*)Cout + o) = v;
+                    *(f32x4*)((float*)Cout + o) = v;
                 }
             }
         }
@@ -196,10 +182,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-// NSTG = 2: double-buffered K loop (64 / 48 KiB LDS, 2-3 workgroups per CU) for the MFMA-bound shapes.
-// NSTG = 1: one stage (34 KiB, 4 workgroups per CU), selectable for small K with MNX_GEMM_1STAGE_K (experiment knob;
-//           not a win overall, see launch_bn).
-template <typename T, int EPI, int BN, int NSTG>
+// Double-buffered K loop (64 / 48 KiB LDS, 2-3 workgroups per CU).
+template <typename T, int EPI, int BN>
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cout,
                                                            const float* __restrict__ bias, const float* resid, int M,
                                                            int N, int K, int tiles_n, int n_tiles) {
@@ -208,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     constexpr int WLD = BN / 32;
     constexpr int STG = (BM + BN) * BK * 2;
     constexpr int EPI_LDS = 34816;    // largest epilogue staging area: 128 rows x (128 x 2 + 16) B = 128 x (64 x 4 + 16) B
-    __shared__ __attribute__((aligned(16))) char smem[NSTG * STG > EPI_LDS ? NSTG * STG : EPI_LDS];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STG > EPI_LDS ? 2 * STG : EPI_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -249,8 +233,8 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
-        if (NSTG == 2 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* ab = smem + (NSTG == 2 ? (kt & 1) * STG : 0);
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* ab = smem + (kt & 1) * STG;
         const char* wb = ab + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -265,165 +249,84 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
         }
         __syncthreads();   // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer kt&1 for tile kt+2
-        if (NSTG == 1 && kt + 1 < nk) {   // single stage: the buffer is free now, refill it and wait
-            issue(kt + 1, 0);
-            __syncthreads();
-        }
     }
     gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
 
-// EXPERIMENT (MNX_GEMM_256=1; not the default): measured 1006 TFLOP/s on 8192^3 (883 for the 2-stage 128x128 kernel)
-// and +8 % on the K <= 256 shapes of stage 1/2, but -10 % on Swin-B's dominant K = 512 shapes: one workgroup per CU
-// leaves the prologue and the epilogue of every tile exposed, and 8 K-tiles do not amortise them.
-// 256x128 tile, 8 waves (4 along M x 2 along N, each 64x64 as above), THREE K-tile stages in a ring (144 KiB of LDS,
-// one workgroup per CU) with counted vmcnt: the 2-stage kernels above spend ~1.1 us per K-tile — the global->LDS
-// latency — because only one tile is in flight while a workgroup computes; here two are, and a tile carries twice the
-// MFMA work per byte staged. One barrier per K-tile: wait for the own DMA pieces of tile kt (vmcnt leaves tile kt+1's
-// six pieces outstanding), barrier (every wave's pieces of tile kt have landed, and every wave has finished reading
-// tile kt-1), re-stage tile kt+2 into the buffer of tile kt-1, compute tile kt.
-template <typename T, int EPI>
-__global__ __launch_bounds__(512) void gemm_tn_256_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cout,
-                                                          const float* __restrict__ bias, const float* resid, int M,
-                                                          int N, int K, int tiles_n, int n_tiles) {
-    typedef typename H16<T>::v8 v8;
-    typedef typename H16<T>::v4 v4;
-    constexpr int TM = 256, TN_ = 128;
-    constexpr int STG = (TM + TN_) * BK * 2;         // 48 KiB per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 * STG
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
-    const int tile = xcd_remap(blockIdx.x, n_tiles);
-    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN_;
-    const int r_in = lane >> 3, p = lane & 7;
-    const T* a_src[4];
-    const T* w_src[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + r_in;
-        a_src[i] = A + (size_t)min(m0 + r, M - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 8 + r_in;
-        w_src[i] = W + (size_t)min(n0 + r, N - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
-    }
-    auto issue = [&](int kt, int stg) {
-        char* ab = smem + stg * STG;
-        char* wb = ab + TM * BK * 2;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + k0), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + k0), (lds_void_t*)(wb + (wave * 2 + i) * 1024), 16, 0, 0);
-    };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nk = K / BK;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
+// fp32 "parity mode" GEMM (compute_dtype FP32): C = epi(A.W^T + b) with fp32 operands on v_mfma_f32_16x16x4_f32 (exact
+// fp32 FMA chains, 1/16 of the bf16 rate). 64x64 tile, 4 waves of 32x32, operands from global memory straight into the
+// fragment layout (lane (fr, fg): float4 at [row fr][k + 4 fg]; the k-slot permutation is the same on both operands).
+// Swapped like the 16-bit kernel (A-operand = W rows) so a lane owns 4 consecutive output columns of one row. Not tuned:
+// it exists so that the whole path can be checked against the reference at fp32 accuracy (tokens exact from pixels).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                       float* Cout, const float* __restrict__ bias, const float* resid,
+                                                       int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    int cur = 0;                                   // stage of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2, cur == 0 ? 2 : cur - 1);   // (kt + 2) % 3 == (cur + 2) % 3
-        const char* ab = smem + cur * STG;
-        const char* wb = ab + TM * BK * 2;
+    const int m0 = blockIdx.y * 64 + (wave & 1) * 32, n0 = blockIdx.x * 64 + (wave >> 1) * 32;
+    const float* ap[2];
+    const float* wp[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v8 af[4], wf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = *(const v8*)(ab + lds_off(wm * 64 + t * 16 + fr, ks * 4 + fg));
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = *(const v8*)(wb + lds_off(wn * 64 + t * 16 + fr, ks * 4 + fg));
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
-        }
-        cur = cur == 2 ? 0 : cur + 1;
+    for (int t = 0; t < 2; ++t) {
+        ap[t] = A + (size_t)min(m0 + t * 16 + fr, M - 1) * K + fg * 4;
+        wp[t] = W + (size_t)min(n0 + t * 16 + fr, N - 1) * K + fg * 4;
     }
-    __syncthreads();                               // every wave is done with the last stage: LDS becomes the staging area
-    // ---- epilogue: transpose through LDS, whole 128-byte lines out (one pass: the staging area is 144 KiB) ----
-    constexpr bool OUT16 = (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16);
-    constexpr int ELT = OUT16 ? 2 : 4;
-    constexpr int ROWB = TN_ * ELT + 16;
-    constexpr int CH_ROW = TN_ * ELT / 16;
+    f32x4 acc[2][2];   // [nt][mt]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int nl = wn * 64 + nt * 16 + fg * 4;
+    for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 16) {           // K % 16 == 0
+        f32x4 a[2], w[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a[t] = *(const f32x4*)(ap[t] + k0);
+            w[t] = *(const f32x4*)(wp[t] + k0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt][j], a[mt][j], acc[nt][mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + nt * 16 + fg * 4;
+        if (n >= N) continue;
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (bias && n0 + nl < N) b4 = *(const f32x4*)(bias + n0 + nl);
+        if (bias) b4 = *(const f32x4*)(bias + n);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int ml = wm * 64 + mt * 16 + fr;
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = m0 + mt * 16 + fr;
+            if (m >= M) continue;
             f32x4 v = acc[nt][mt] + b4;
-            if (EPI == EPI_GELU_16) {
-                v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
-            }
-            if (OUT16) {
-                v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                *(v4*)(smem + ml * ROWB + nl * 2) = o4;
-            } else {
-                *(f32x4*)(smem + ml * ROWB + nl * 4) = v;
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM * CH_ROW / 512; ++i) {
-        const int id = tid + i * 512;
-        const int rl = id / CH_ROW, ch = id % CH_ROW;
-        const int m = m0 + rl;
-        const int n = n0 + ch * (16 / ELT);
-        if (m < M && n < N) {
+            if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
             const size_t o = (size_t)m * N + n;
-            if (OUT16) {
-                *(v8*)((T*)Cout + o) = *(const v8*)(smem + rl * ROWB + ch * 16);
-            } else {
-                f32x4 v = *(const f32x4*)(smem + rl * ROWB + ch * 16);
-                if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
-                *(f32x4*)((float*)Cout + o) = v;
-            }
+            if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
+            *(f32x4*)(Cout + o) = v;
         }
     }
 }
 
-template <typename T>
-static hipError_t launch_256(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
+static hipError_t launch_f32(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
                              int M, int N, int K, hipStream_t s) {
-    constexpr int LDS = 3 * (256 + 128) * BK * 2;
-    const int tm = (M + 255) / 256, tn = (N + 127) / 128;
-    dim3 grid(tm * tn), block(512);
-#define MNX_GEMM256_CASE(E)                                                                                               \
-    case E: {                                                                                                             \
-        static bool attr_set = false;                                                                                     \
-        if (!attr_set) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_256_kernel<T, E>,                                     \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                          \
-            if (e != hipSuccess) return e;                                                                                \
-            attr_set = true;                                                                                              \
-        }                                                                                                                 \
-        hipLaunchKernelGGL((gemm_tn_256_kernel<T, E>), grid, block, LDS, s, (const T*)A, (const T*)W, C, bias, resid, M,  \
-                           N, K, tn, tm * tn);                                                                            \
-        break;                                                                                                            \
-    }
+    if ((K & 15) || (N & 3)) return hipErrorInvalidValue;
+    dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+#define MNX_F32_CASE(E)                                                                                                   \
+    case E:                                                                                                               \
+        hipLaunchKernelGGL((gemm_f32_kernel<E>), grid, block, 0, s, (const float*)A, (const float*)W, (float*)C, bias,    \
+                           resid, M, N, K);                                                                               \
+        break;
     switch (epi) {
-        MNX_GEMM256_CASE(EPI_BIAS_16)
-        MNX_GEMM256_CASE(EPI_GELU_16)
-        MNX_GEMM256_CASE(EPI_RESID_F32)
-        MNX_GEMM256_CASE(EPI_BIAS_F32)
+        MNX_F32_CASE(EPI_BIAS_16)
+        MNX_F32_CASE(EPI_GELU_16)
+        MNX_F32_CASE(EPI_RESID_F32)
+        MNX_F32_CASE(EPI_BIAS_F32)
         default: return hipErrorInvalidValue;
     }
-#undef MNX_GEMM256_CASE
+#undef MNX_F32_CASE
     return hipGetLastError();
 }
 
@@ -432,18 +335,11 @@ static hipError_t launch_bn(int epi, const void* A, const void* W, void* C, cons
                             int M, int N, int K, hipStream_t s) {
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
-    const bool glds = (K % BK) == 0 && getenv("MNX_NO_GLDS") == nullptr;
-    // measured at B=64 (tools/gemm_bench.py): one stage helps the bias-only epilogue at K <= 256 by 2-5 % and costs the
-    // GELU epilogue 8-15 % (those launches are bound by the epilogue's VALU + store phase, not by residency): off
-    static const int one_stage_k = getenv("MNX_GEMM_1STAGE_K") ? atoi(getenv("MNX_GEMM_1STAGE_K")) : 0;
-    const bool one = K <= one_stage_k;
+    const bool glds = (K % BK) == 0;
 #define MNX_GEMM_CASE(E)                                                                                                  \
     case E:                                                                                                               \
-        if (glds && one)                                                                                                  \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN, 1>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, \
-                               resid, M, N, K, tn, tm * tn);                                                              \
-        else if (glds)                                                                                                    \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN, 2>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, \
+        if (glds)                                                                                                         \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias,    \
                                resid, M, N, K, tn, tm * tn);                                                              \
         else                                                                                                              \
             hipLaunchKernelGGL((gemm_tn_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid,  \
@@ -465,11 +361,6 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
                            int M, int N, int K, hipStream_t s) {
     // tile choice: 128x128 unless its tile count leaves the 512 resident-workgroup slots (256 CUs x 2) badly
     // quantised; then 128x64 tiles (3 workgroups per CU)
-    static const int use256 = getenv("MNX_GEMM_256") ? atoi(getenv("MNX_GEMM_256")) : 0;   // experiment knob
-    if (use256 && (K % BK) == 0 && K >= 2 * BK && N % 8 == 0) return launch_256<T>(epi, A, W, C, bias, resid, M, N, K, s);
-    static const int force_bn = getenv("MNX_GEMM_BN") ? atoi(getenv("MNX_GEMM_BN")) : 0;   // A/B knob (tools)
-    if (force_bn == 64 && N >= 64) return launch_bn<T, 64>(epi, A, W, C, bias, resid, M, N, K, s);
-    if (force_bn == 128) return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const double waves128 = (double)t128 / 512.0;
     const bool small = t128 < 512 || (waves128 < 3.0 && (waves128 - (long)waves128) > 0.0 && (waves128 - (long)waves128) < 0.6);
@@ -477,11 +368,10 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
     return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
 }
 
-void set_gemm_ablate(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &v, sizeof(int)); }
-
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                          const float* resid, int M, int N, int K, hipStream_t s) {
     if ((K & 7) || (N & 7) || M <= 0) return hipErrorInvalidValue;
+    if (dtype == MNX_DT_F32) return launch_f32(epi, A, W, C, bias, resid, M, N, K, s);
     return dtype == MNX_DT_F16 ? launch_t<f16_t>(epi, A, W, C, bias, resid, M, N, K, s)
                                : launch_t<bf16_t>(epi, A, W, C, bias, resid, M, N, K, s);
 }

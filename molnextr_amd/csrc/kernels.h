@@ -5,7 +5,8 @@
 
 namespace mnx {
 
-enum { MNX_DT_BF16 = 0, MNX_DT_F16 = 1 };
+enum { MNX_DT_BF16 = 0, MNX_DT_F16 = 1, MNX_DT_F32 = 2 };   // F32: parity mode, every encoder operand in fp32
+inline size_t dt_size(int dtype) { return dtype == MNX_DT_F32 ? 4 : 2; }
 enum { EPI_BIAS_16 = 0, EPI_GELU_16 = 1, EPI_RESID_F32 = 2, EPI_BIAS_F32 = 3 };
 
 // ---- gemm.hip -------------------------------------------------------------------------------
@@ -30,7 +31,8 @@ hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStre
 
 // ---- preprocess.hip -------------------------------------------------------------------------
 // HWC uint8 RGB page -> [3,S,S] fp32 (CropWhite(pad) + bilinear resize + gray + ImageNet normalise); bbox: 4 ints scratch
-hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int pad, int S, int* bbox, float* out, hipStream_t s);
+hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int pad, int square, int S, int* bbox, int* crop_out,
+                             float* out, hipStream_t s);
 
 // ---- decoder.hip ----------------------------------------------------------------------------
 struct DecWeights;   // device pointers, see engine.cpp

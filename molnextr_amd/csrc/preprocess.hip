@@ -1,5 +1,5 @@
 // preprocess.hip — the transform in front of the encoder, on device:
-//   CropWhite(pad) -> Resize(S,S, bilinear) -> ToGray -> Normalize(ImageNet) -> CHW fp32
+//   CropWhite(pad) [-> PadToSquare] -> Resize(S,S, bilinear) -> ToGray -> Normalize(ImageNet) -> CHW fp32
 //   reference MolNexTR/dataset.py:158-185 (augment=False), MolNexTR/data_aug.py:98-143, MolNexTR/model.py:104.
 // Integer / byte work, HBM-trivial (one pass over the page for the bounding box, then 4 taps per output pixel).
 // It computes bit for bit what molnextr_amd/preprocess.py computes (the host restatement of albumentations 1.1.0 /
@@ -58,22 +58,31 @@ __device__ __forceinline__ void linear_tap(int d, int src, int dst, int& i0, int
 struct PrepArgs {
     const uint8_t* rgb;
     const int* bbox;
+    int* crop_out;       // or null: {crop_top, crop_bottom, crop_left, crop_right} as CropWhite.update_params reports
     float* out;          // [3, S, S]
-    int H, W, pad, S;
+    int H, W, pad, S, square;
     float mean255[3], inv[3];
 };
 
 __global__ __launch_bounds__(256) void prep_resize_kernel(PrepArgs a) {
     const int dx = blockIdx.x * 16 + (threadIdx.x & 15), dy = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (dx >= a.S || dy >= a.S) return;
     int top = 0, bottom = a.H, left = 0, right = a.W;
     if (a.bbox[1] >= 0) { top = a.bbox[0]; bottom = a.bbox[1] + 1; left = a.bbox[2]; right = a.bbox[3] + 1; }
-    const int hc = bottom - top, wc = right - left, Hp = hc + 2 * a.pad, Wp = wc + 2 * a.pad;
+    const int hc = bottom - top, wc = right - left;
+    if (a.crop_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        a.crop_out[0] = top; a.crop_out[1] = a.H - bottom; a.crop_out[2] = left; a.crop_out[3] = a.W - right;
+    }
+    int Hp = hc + 2 * a.pad, Wp = wc + 2 * a.pad, pad_t = a.pad, pad_l = a.pad;
+    if (a.square) {      // PadToSquare after CropWhite (reference data_aug.py:286-301): diff//2 first, the rest after
+        const int diff = Hp > Wp ? Hp - Wp : Wp - Hp;
+        if (Hp <= Wp) { pad_t += diff / 2; Hp = Wp; } else { pad_l += diff / 2; Wp = Hp; }
+    }
+    if (dx >= a.S || dy >= a.S) return;
     int y0, y1, wy0, wy1, x0, x1, wx0, wx1;
     linear_tap(dy, Hp, a.S, y0, y1, wy0, wy1);
     linear_tap(dx, Wp, a.S, x0, x1, wx0, wx1);
     auto px = [&](int y, int x, int c) -> int {      // the cropped page with its white border, never materialised
-        y -= a.pad; x -= a.pad;
+        y -= pad_t; x -= pad_l;
         if (y < 0 || y >= hc || x < 0 || x >= wc) return 255;
         return a.rgb[((size_t)(top + y) * a.W + left + x) * 3 + c];
     };
@@ -91,11 +100,12 @@ __global__ __launch_bounds__(256) void prep_resize_kernel(PrepArgs a) {
     for (int c = 0; c < 3; ++c) a.out[((size_t)c * a.S + dy) * a.S + dx] = (g - a.mean255[c]) * a.inv[c];
 }
 
-hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int pad, int S, int* bbox, float* out, hipStream_t s) {
+hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int pad, int square, int S, int* bbox, int* crop_out,
+                             float* out, hipStream_t s) {
     hipLaunchKernelGGL(prep_bbox_init_kernel, dim3(1), dim3(64), 0, s, bbox, H, W);
     hipLaunchKernelGGL(prep_bbox_kernel, dim3(H), dim3(256), 0, s, rgb, H, W, bbox);
     PrepArgs a;
-    a.rgb = rgb; a.bbox = bbox; a.out = out; a.H = H; a.W = W; a.pad = pad; a.S = S;
+    a.rgb = rgb; a.bbox = bbox; a.crop_out = crop_out; a.out = out; a.H = H; a.W = W; a.pad = pad; a.S = S; a.square = square;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};   // IMAGENET_DEFAULT_MEAN / STD
     for (int c = 0; c < 3; ++c) {
         volatile float m = mean[c] * 255.0f, d = sd[c] * 255.0f;   // fp32 products, as numpy computes them

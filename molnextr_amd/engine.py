@@ -18,7 +18,7 @@ from . import weights as W
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmolnextr_hip.so")
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
            "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess")
@@ -84,7 +84,7 @@ def load_library():
     lib.mnx_atom_scan.restype = C.c_int
     lib.mnx_atom_scan.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.mnx_preprocess.restype = C.c_int
-    lib.mnx_preprocess.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.mnx_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.mnx_decode_beam.restype = C.c_int
     lib.mnx_decode_beam.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.mnx_predict.restype = C.c_int
@@ -132,7 +132,7 @@ class Engine:
         cfg.dec_layers, cfg.dec_dim, cfg.dec_heads, cfg.dec_ff = dec.layers, dec.d_model, dec.heads, dec.d_ff
         cfg.vocab, cfg.sym_offset, cfg.coord_bins, cfg.pe_len = dec.vocab, dec.vocab - 128, 64, dec.pe_len
         cfg.max_len, cfg.max_batch, cfg.max_atoms = max_len, max_batch, max_atoms
-        cfg.compute_dtype = {"bf16": 0, "fp16": 1}[dtype]
+        cfg.compute_dtype = {"bf16": 0, "fp16": 1, "fp32": 2}[dtype]
         cfg.dec_slots = dec_slots
         self.dtype = dtype
         keep, descs = [], []
@@ -223,22 +223,26 @@ class Engine:
         return {"tokens": tokens, "lengths": lengths, "token_logp": logp, "hidden": hidden, "logits": trace}
 
     # -- CropWhite + Resize + ToGray + Normalize on device ---------------------------------------------
-    def preprocess(self, images, pad: int = 50) -> torch.Tensor:
-        """List of HWC uint8 RGB pages (numpy arrays or tensors, any sizes) -> [n,3,S,S] fp32 on the device."""
+    def preprocess(self, images, pad: int = 50, pad_to_square: bool = False, return_crops: bool = False):
+        """List of HWC uint8 RGB pages (numpy arrays or tensors, any sizes) -> [n,3,S,S] fp32 on the device.
+        pad_to_square: PadToSquare after CropWhite (the reference's transform for real/acs.csv and real/UOB.csv).
+        return_crops: also return the CropWhite parameters [n,4] (crop_top, crop_bottom, crop_left, crop_right)."""
         dev = torch.device("cuda", self.device)
         S = self.enc.img_size
         out = torch.empty(len(images), 3, S, S, dtype=torch.float32, device=dev)
+        crops = torch.zeros(len(images), 4, dtype=torch.int32, device=dev) if return_crops else None
         keep = []
         for i, im in enumerate(images):
-            t = torch.as_tensor(im)
+            t = torch.as_tensor(np.ascontiguousarray(im))
             if t.dim() == 2:
                 t = t[..., None].expand(-1, -1, 3)
             t = t[..., :3].to(dtype=torch.uint8).contiguous().to(dev, non_blocking=True)
             keep.append(t)
-            self._check(self.lib.mnx_preprocess(self.h, _ptr(t), t.shape[0], t.shape[1], pad, _ptr(out[i]), _stream()),
+            self._check(self.lib.mnx_preprocess(self.h, _ptr(t), t.shape[0], t.shape[1], pad, int(pad_to_square),
+                                                _ptr(crops[i]) if return_crops else None, _ptr(out[i]), _stream()),
                         "mnx_preprocess")
         torch.cuda.current_stream().synchronize()      # the uploaded pages must outlive the kernels
-        return out
+        return (out, crops) if return_crops else out
 
     # -- TransformerDecoderAR.decode, beam_size > 1 --------------------------------------------------
     def decode_beam(self, features: torch.Tensor, beam: int = 5, n_best: int = 1, max_len: Optional[int] = None,

@@ -68,10 +68,14 @@ def dumps_field(obj) -> Optional[str]:
     return json.dumps(round_floats(obj)).replace(" ", "")
 
 
+PAD_TO_SQUARE_FILES = ("real/acs.csv", "real/UOB.csv")     # reference dataset.py:163-164
+
+
 def run_inference(engine, load_image: Callable[[int], np.ndarray], n_items: int, batch_size: int, rank: int = 0,
-                  world: int = 1, tokenizer=None, group: int = 512) -> Dict[int, dict]:
+                  world: int = 1, tokenizer=None, group: int = 512, pad_to_square: bool = False) -> Dict[int, dict]:
     """valid_fn for this rank's shard, then the gather: returns {dataset index: prediction dict} on every rank
-    (the reference keeps it on all ranks too, main.py:295-301). `engine`: molnextr_amd.engine.Engine."""
+    (the reference keeps it on all ranks too, main.py:295-301). `engine`: molnextr_amd.engine.Engine.
+    pad_to_square: the PadToSquare step `get_transforms` inserts for the test files in PAD_TO_SQUARE_FILES."""
     tok = (tokenizer or get_tokenizer())["chartok_coords"]
     ref_batch = batch_size * 2
     if ref_batch > engine.ROWS_PER_DECODE:
@@ -81,13 +85,13 @@ def run_inference(engine, load_image: Callable[[int], np.ndarray], n_items: int,
     kmax = engine.max_atoms
     recs = []
     step = max(group // ref_batch, 1) * ref_batch          # whole reference batches per engine call
+    dev = getattr(engine, "torch_device", None) or torch.device("cuda", engine.device)
     for g0 in range(0, len(mine), step):
         ids = mine[g0:g0 + step]
-        x = engine.preprocess([load_image(i) for i in ids])
+        x = engine.preprocess([load_image(i) for i in ids], pad_to_square=pad_to_square)
         out = engine.predict(x, ref_batch=ref_batch)
         recs.append(shard.pack_records_device(out["tokens"], out["lengths"], out["atom_idx"], out["n_atoms"],
                                               out["edges"]))
-    dev = torch.device("cuda", engine.device)
     rec = torch.cat(recs) if recs else torch.zeros(0, shard.record_words(kmax), dtype=torch.int32, device=dev)
     index = torch.tensor(mine, dtype=torch.int32, device=dev).view(-1, 1)
     rec = torch.cat([index, rec], dim=1).contiguous()      # the dataset index travels with its record
@@ -160,7 +164,8 @@ def main(argv=None):
     ap.add_argument("--data_path", default=".")
     ap.add_argument("--test_file", required=True, help="CSV with file_path (and SMILES / image_id) columns")
     ap.add_argument("--save_path", default="predict_output")
-    ap.add_argument("--load_path", default=None, help="reference checkpoint (.pth); default: synthetic checkpoint")
+    ap.add_argument("--load_path", required=True,
+                    help="checkpoint: reference .pth or .safetensors; 'synthetic' = deterministic test weights")
     ap.add_argument("--batch_size", type=int, default=4, help="per-GPU batch size; inference uses twice that")
     args = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,11 +175,13 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    states = torch.load(args.load_path, map_location="cpu") if args.load_path else W.synthetic_checkpoint(0)
+    from .checkpoint import load_checkpoint               # strict validation, no optimizer state, safetensors-aware
+    states = W.synthetic_checkpoint(0) if args.load_path == "synthetic" else load_checkpoint(args.load_path)
     engine = Engine(states["encoder"], states["decoder"], device=local, max_batch=64)
     df = pd.read_csv(os.path.join(args.data_path, args.test_file))
     paths = [os.path.join(args.data_path, p) for p in df["file_path"]]
-    preds = run_inference(engine, lambda i: load_image_rgb(paths[i]), len(df), args.batch_size, rank, world)
+    preds = run_inference(engine, lambda i: load_image_rgb(paths[i]), len(df), args.batch_size, rank, world,
+                          pad_to_square=args.test_file in PAD_TO_SQUARE_FILES)
     if rank == 0:
         if "image_id" not in df.columns:    # main.py:461-462
             df["image_id"] = [p.split("/")[-1].split(".")[0] for p in df["file_path"]]

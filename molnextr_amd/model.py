@@ -120,13 +120,18 @@ def predict_pipeline(engine: Engine, images: torch.Tensor, tokenizer=None, ref_b
 class molnextr:
     """Main interface (reference MolNexTR/model.py:33-196).
 
-    model_path: a checkpoint in the reference's format ({'encoder','decoder','args'}); or None / 'synthetic' for
-    the deterministic synthetic checkpoint (no pretrained weights exist offline).
-    device: torch.device('cuda', i) — an MI355X is required."""
+    model_path: a checkpoint in the reference's format ({'encoder','decoder','args'}, `.pth`) or our `.safetensors`;
+    the literal 'synthetic' opts into the deterministic hash-generated checkpoint (tests / bench only: its predictions
+    are meaningless as chemistry). There is no default: like the reference, the model cannot run without weights.
+    device: torch.device('cuda', i) — an MI355X is required.
+    dtype: 'bf16' (throughput mode), 'fp16', or 'fp32' (parity mode: tokens / atoms / bonds equal the reference's)."""
 
-    def __init__(self, model_path=None, device=None, max_batch: int = 32, dtype: str = "bf16",
+    def __init__(self, model_path, device=None, max_batch: int = 32, dtype: str = "bf16",
                  device_preprocess: bool = True):
-        if model_path in (None, "synthetic"):
+        if model_path is None:
+            raise ValueError("molnextr(model_path): a checkpoint path is required (pass 'synthetic' explicitly for the "
+                             "deterministic test checkpoint)")
+        if model_path == "synthetic":
             states = W.synthetic_checkpoint(0)
         else:
             from .checkpoint import load_checkpoint      # .pth in the reference format or our .safetensors; strict
@@ -167,11 +172,19 @@ class molnextr:
 
     def predict_images(self, input_images: List, return_atoms_bonds=False, return_confidence=False, batch_size=16):
         preds: List[dict] = []
-        batch_size = min(batch_size, ROWS, self.engine.max_batch)
+        if len(input_images) == 0:
+            return []                                      # reference model.py:101-102: empty loop, empty list
+        cap = min(ROWS, self.engine.max_batch)
+        if batch_size < 1 or batch_size > cap:
+            # results depend on the row inside the reference batch (positional-encoding quirk), so a silently
+            # different batch size would silently change tokens
+            raise ValueError(f"batch_size must be 1..{cap} (one reference batch per {ROWS}-row decode tile); got {batch_size}")
         if not return_confidence:
-            # throughput path: all images at once, reference batches of `batch_size` kept as numbering units
-            for i in range(0, len(input_images), 1024):
-                x = self._transform(input_images[i:i + 1024])
+            # throughput path: many images per engine call, reference batches of `batch_size` kept as numbering units;
+            # the group is a whole number of reference batches so that batch boundaries do not drift between groups
+            group = (1024 // batch_size) * batch_size
+            for i in range(0, len(input_images), group):
+                x = self._transform(input_images[i:i + group])
                 preds += predict_pipeline(self.engine, x, self.tokenizer, ref_batch_size=batch_size)
         else:
             step = max(self.engine.max_batch // batch_size, 1) * batch_size

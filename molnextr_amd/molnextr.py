@@ -3,9 +3,9 @@
 Same names, arguments and result keys. Differences, on purpose:
   * the model runs on an MI355X through libmolnextr_hip.so only — there is no MPS / CPU detection and NO CPU
     fallback on error (reference molnextr.py:179-189,256-268): errors propagate;
-  * the checkpoint is taken from $MOLNEXTR_CHECKPOINT (reference format); without it the deterministic synthetic
-    checkpoint is used — the reference downloads molnextr_best.pth at run time (molnextr.py:129-143), which is
-    impossible offline;
+  * the checkpoint is taken from $MOLNEXTR_CHECKPOINT (reference `.pth` or our `.safetensors`); the reference downloads
+    molnextr_best.pth at run time (molnextr.py:129-143), which is impossible offline. Without the variable the call
+    raises — MOLNEXTR_CHECKPOINT=synthetic opts into the deterministic hash-generated weights (tests only);
   * `bond_sets` IS returned with atoms_bonds=True (the reference computes it but drops it).
 """
 import logging
@@ -29,7 +29,10 @@ class MolNexTRSingleton:
             cls._detect_hardware()
             from .model import molnextr
             path = os.environ.get("MOLNEXTR_CHECKPOINT")
-            logger.info("Initializing MolNexTR (%s) on %s", path or "synthetic checkpoint", cls._device_name)
+            if not path:
+                raise RuntimeError("set MOLNEXTR_CHECKPOINT to a MolNexTR checkpoint (reference .pth or .safetensors); "
+                                   "MOLNEXTR_CHECKPOINT=synthetic selects the deterministic test weights")
+            logger.info("Initializing MolNexTR (%s) on %s", path, cls._device_name)
             cls._instance = molnextr(path, cls._device)
         return cls._instance
 

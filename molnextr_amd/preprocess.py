@@ -1,4 +1,4 @@
-"""Host pre-processing in front of the device path ("next" row — restated, not yet pinned).
+"""Host pre-processing in front of the device path.
 
   CropWhite(pad=50) -> Resize(384,384, bilinear) -> ToGray -> Normalize(ImageNet) -> CHW float32
   (reference MolNexTR/dataset.py:158-185 with augment=False, MolNexTR/data_aug.py:98-143, MolNexTR/model.py:104)
@@ -7,7 +7,10 @@ The reference runs these through albumentations 1.1.0 / OpenCV, neither of which
 restated from their documented behaviour: `cv2.resize(INTER_LINEAR)` on uint8 = half-pixel-centre bilinear with
 11-bit fixed-point weights and OpenCV's two-pass integer arithmetic (its 2x-decimation special case, which
 switches to area averaging for exact integer scale 2, is NOT restated); `cv2.cvtColor(RGB2GRAY)` = (R*4899 + G*9617 + B*1868 + 8192) >> 14; Normalize =
-(x/255 - mean) / std. PARITY UNPINNED until a box with OpenCV can produce fixtures.
+(x/255 - mean) / std. CropWhite and PadToSquare ARE pinned: tools/gen_golden.py drives the reference's own classes
+(MolNexTR/data_aug.py) on ragged pages and tests/test_preprocess.py checks crop boxes, shapes and content hashes
+(tests/golden/crop_pad.json). The OpenCV resize / gray arithmetic stays UNPINNED until a box with OpenCV can produce
+fixtures.
 """
 import numpy as np
 
@@ -15,26 +18,40 @@ MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
 STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
 
 
-def crop_white(img: np.ndarray, pad: int = 50, value=(255, 255, 255)) -> np.ndarray:
-    """Crop to the bounding box of non-white pixels, then pad `pad` white pixels on every side."""
+def crop_box(img: np.ndarray, value=(255, 255, 255)):
+    """(crop_top, crop_bottom, crop_left, crop_right) as CropWhite.update_params reports them (reference
+    data_aug.py:106-136): rows / columns to drop on each side so that the bounding box of every pixel that differs
+    from `value` in ANY channel remains; all zero for a blank page. Pinned by tests/golden/crop_pad.json."""
     h, w, _ = img.shape
-    ink = (img != np.array(value, dtype=img.dtype)).sum(axis=2)
-    if ink.sum() != 0:
-        rows, cols = ink.sum(axis=1), ink.sum(axis=0)
-        top = 0
-        while rows[top] == 0 and top + 1 < h:
-            top += 1
-        bottom = h
-        while rows[bottom - 1] == 0 and bottom - 1 > top:
-            bottom -= 1
-        left = 0
-        while cols[left] == 0 and left + 1 < w:
-            left += 1
-        right = w
-        while cols[right - 1] == 0 and right - 1 > left:
-            right -= 1
-        img = img[top:bottom, left:right]
-    return np.pad(img, ((pad, pad), (pad, pad), (0, 0)), mode="constant", constant_values=value[0])
+    ink = (img != np.asarray(value, dtype=img.dtype)).any(axis=2)
+    rows, cols = np.flatnonzero(ink.any(axis=1)), np.flatnonzero(ink.any(axis=0))
+    if rows.size == 0:
+        return 0, 0, 0, 0
+    return int(rows[0]), int(h - 1 - rows[-1]), int(cols[0]), int(w - 1 - cols[-1])
+
+
+def _pad_white(img: np.ndarray, top: int, bottom: int, left: int, right: int, value=(255, 255, 255)) -> np.ndarray:
+    h, w, c = img.shape
+    out = np.empty((h + top + bottom, w + left + right, c), dtype=img.dtype)
+    out[...] = np.asarray(value, dtype=img.dtype)
+    out[top:top + h, left:left + w] = img
+    return out
+
+
+def crop_white(img: np.ndarray, pad: int = 50, value=(255, 255, 255)) -> np.ndarray:
+    """CropWhite(pad): crop to the ink bounding box, then a white border of `pad` pixels (data_aug.py:138-143)."""
+    h, w, _ = img.shape
+    t, b, l, r = crop_box(img, value)
+    return _pad_white(img[t:h - b, l:w - r], pad, pad, pad, pad, value)
+
+
+def pad_to_square(img: np.ndarray, value=(255, 255, 255)) -> np.ndarray:
+    """PadToSquare (reference data_aug.py:286-301, inserted after CropWhite for 'real/acs.csv' and 'real/UOB.csv',
+    dataset.py:163-164): the shorter side grows to the longer one, diff//2 white pixels first, the rest after."""
+    h, w, _ = img.shape
+    diff = abs(h - w)
+    p1, p2 = diff // 2, diff - diff // 2
+    return _pad_white(img, p1, p2, 0, 0, value) if h <= w else _pad_white(img, 0, 0, p1, p2, value)
 
 
 def _linear_coeffs(src: int, dst: int):
@@ -74,12 +91,15 @@ def to_gray_rgb(img: np.ndarray) -> np.ndarray:
     return np.repeat(g.astype(np.uint8)[..., None], 3, axis=2)
 
 
-def transform_image(img: np.ndarray, input_size: int = 384) -> np.ndarray:
-    """HWC uint8 RGB -> CHW float32, normalised: the tensor the device path takes."""
+def transform_image(img: np.ndarray, input_size: int = 384, square: bool = False) -> np.ndarray:
+    """HWC uint8 RGB -> CHW float32, normalised: the tensor the device path takes. square: PadToSquare after CropWhite."""
     if img.ndim == 2:
         img = np.repeat(img[..., None], 3, axis=2)
     img = np.ascontiguousarray(img[..., :3], dtype=np.uint8)
-    x = to_gray_rgb(resize_bilinear_u8(crop_white(img, 50), input_size)).astype(np.float32)
+    page = crop_white(img, 50)
+    if square:
+        page = pad_to_square(page)
+    x = to_gray_rgb(resize_bilinear_u8(page, input_size)).astype(np.float32)
     x = (x - MEAN * 255.0) * (1.0 / (STD * 255.0))
     return np.ascontiguousarray(x.transpose(2, 0, 1), dtype=np.float32)
 

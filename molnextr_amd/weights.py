@@ -352,3 +352,39 @@ def synthetic_images(batch: int, size: int = 384, first_index: int = 0) -> torch
         for c in range(3):
             out[i, c] = (g / 255.0 - mean[c]) / std[c]
     return torch.from_numpy(out)
+
+
+PAGE_CASES = [(470, 923, "strokes"), (64, 64, "strokes"), (1, 1, "blank"), (1, 1, "ink"), (37, 911, "strokes"),
+              (600, 800, "strokes"), (384, 384, "border"), (300, 17, "strokes"), (50, 70, "blank"), (40, 40, "corners"),
+              (90, 120, "noise"), (33, 200, "row"), (200, 33, "col"), (120, 120, "offwhite"), (211, 97, "channel")]
+
+
+def synthetic_page(case: int) -> np.ndarray:
+    """Ragged HWC uint8 RGB test pages (white paper with ink), a pure function of the case index: inputs of the
+    pre-processing fixtures (CropWhite / PadToSquare, reference MolNexTR/data_aug.py:98-150,286-301)."""
+    h, w, kind = PAGE_CASES[case]
+    img = np.full((h, w, 3), 255, np.uint8)
+    u = hash_uniform(f"page{case}", 6 * 12 + h * w * 3 if kind == "noise" else 6 * 12)
+    if kind == "strokes":
+        for s in range(12):
+            y, x, hh, ww, r, g = u[6 * s:6 * s + 6]
+            y, x = int(y * h), int(x * w)
+            hh, ww = 1 + int(hh * max(1, h // 3)), 1 + int(ww * max(1, w // 3))
+            img[y:y + hh, x:x + ww] = (int(r * 256), int(g * 256), int((r + g) * 128) % 256)
+    elif kind == "ink":
+        img[0, 0] = 0
+    elif kind == "border":          # ink on all four page borders
+        img[0, 5:9] = 0; img[-1, 100] = 10; img[7, 0] = 20; img[200, -1] = 30
+    elif kind == "corners":
+        img[0, 0] = 0; img[-1, -1] = 254
+    elif kind == "noise":
+        img = (u[72:].reshape(h, w, 3) * 256).astype(np.uint8)
+    elif kind == "row":
+        img[h // 2, 3:w - 7] = 0
+    elif kind == "col":
+        img[5:h - 2, w // 2] = 0
+    elif kind == "offwhite":        # a pixel that differs from white in ONE channel only counts as ink
+        img[30, 40] = (255, 255, 254); img[90, 70, 0] = 254
+    elif kind == "channel":
+        img[20:25, 10:60, 1] = 0
+    return img

@@ -42,3 +42,72 @@ def test_prediction_table_and_csv(tmp_path):
     assert out.endswith("prediction_acs.csv") and list(df["image_id"]) == ["a", "b", "c"]
     assert json.loads(df["node_symbols"][0]) == ["C", "C"]
     assert json.load(open(tmp_path / "eval_scores_acs_best.json"))["raw_string_match"] == pytest.approx(2 / 3)
+
+
+# ---- run_inference's index bookkeeping across ranks (gloo, CPU): padded duplicates, n not divisible -----------------
+class _FakeEngine:
+    """Stands in for molnextr_amd.engine.Engine on the CPU: 'decodes' image i into the token sequence [5 + i % 90, 2]
+    and records the reference batches it was handed (they are part of the parity contract)."""
+    ROWS_PER_DECODE = 32
+    max_atoms = 8
+    torch_device = torch.device("cpu")
+
+    def __init__(self):
+        self.batches = []
+
+    def preprocess(self, images, pad_to_square=False):
+        return torch.tensor([int(im[0, 0, 0]) * 256 + int(im[0, 0, 1]) for im in images], dtype=torch.int32)
+
+    def predict(self, x, ref_batch=32, max_len=None):
+        n = x.shape[0]
+        self.batches += [x[i:i + ref_batch].tolist() for i in range(0, n, ref_batch)]
+        tokens = torch.zeros(n, 480, dtype=torch.int32)
+        tokens[:, 0] = 5 + x % 90
+        tokens[:, 1] = 2
+        return {"tokens": tokens, "lengths": torch.full((n,), 2, dtype=torch.int32),
+                "n_atoms": torch.zeros(n, dtype=torch.int32), "atom_idx": torch.zeros(n, 8, dtype=torch.int32),
+                "edges": torch.zeros(n, 8, 8, dtype=torch.uint8)}
+
+
+def _page(i):
+    import numpy as np
+    p = np.zeros((2, 2, 3), np.uint8)
+    p[0, 0, 0], p[0, 0, 1] = i // 256, i % 256
+    return p
+
+
+def _eval_worker(rank, world, n, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _FakeEngine()
+    preds = E.run_inference(eng, _page, n, batch_size=2, rank=rank, world=world, group=8)
+    q.put((rank, {i: p["chartok_coords"]["smiles"] for i, p in preds.items()}, eng.batches))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 7), (3, 10), (3, 2)])
+def test_run_inference_index_bookkeeping_gloo(world, n):
+    """Every rank ends up with exactly one prediction per dataset index (the sampler's wrap-around duplicates overwrite
+    themselves, as in the reference main.py:295-301), each from ITS image, and the engine saw exactly the reference
+    batches DistributedSampler + DataLoader(batch_size*2) would have produced on that rank."""
+    import os
+    import torch.multiprocessing as mp
+    from molnextr_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer()["chartok_coords"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() * 7 + world * 13 + n) % 2000
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, n, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = {i: tok.sequence_to_smiles([5 + i % 90, 2])["smiles"] for i in range(n)}
+    for rank, smiles, batches in got:
+        assert smiles == want, f"rank {rank}"
+        assert batches == E.reference_batches(E.sampler_indices(n, rank, world), batch_size=2), f"rank {rank}"

@@ -70,43 +70,6 @@ def test_gemm_all_epilogues(eng, dev, M, N, K):
     assert (r2 - (ref + res)).abs().max().item() < 2e-4
 
 
-def test_gemm_256x128_three_stage_variant_in_subprocess():
-    """The 256x128-tile, 3-stage-ring GEMM (MNX_GEMM_256=1, an experiment knob read once per process: 1006 TFLOP/s on
-    8192^3 but slower than the 128x128 kernel on Swin-B's K=512 shapes, so not the default) must stay exact."""
-    import subprocess
-    import sys
-    code = """
-import torch
-from molnextr_amd import weights as W
-from molnextr_amd.engine import Engine
-TINY = W.EncoderDims(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)
-dec = W.DecoderDims(enc_dim=TINY.num_features)
-ck = W.synthetic_checkpoint(0, enc=TINY, dec=dec)
-eng = Engine(ck["encoder"], ck["decoder"], max_batch=2, enc=TINY, dec=dec)
-for (M, N, K) in [(4608, 1024, 4096), (18432, 2048, 512), (1000, 384, 128), (640, 768, 256), (2304, 128, 512), (70000, 256, 256)]:
-    for epi in (0, 1, 2, 3):
-        g = torch.Generator().manual_seed(M + N + K + epi)
-        A = torch.randn(M, K, generator=g).cuda().bfloat16()
-        Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().bfloat16()
-        bias = torch.randn(N, generator=g).cuda()
-        ref = A.float() @ Wt.float().t() + bias
-        if epi == 1:
-            ref = torch.nn.functional.gelu(ref)
-        out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 2 else torch.bfloat16)
-        if epi == 2:
-            out.normal_(generator=None)
-            ref = ref + out
-        eng.gemm16(epi, A, Wt, out, bias)
-        err = (out.float() - ref).abs().max().item()
-        tol = 2e-4 if epi >= 2 else 3e-2
-        assert err < tol, (M, N, K, epi, err)
-print("ok")
-"""
-    env = dict(os.environ, MNX_GEMM_256="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("dtype,tol", [("bf16", 4e-2), ("fp16", 6e-3)])
 def test_swin_tiny_every_block_vs_reference_golden(golden_dir, dev, dtype, tol):
     gold = np.load(os.path.join(golden_dir, "swin_tiny.npz"))
@@ -222,7 +185,10 @@ def test_beam1_equals_greedy(eng, dev):
         assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
 
 
-@pytest.mark.parametrize("B,beam,n_best,max_len", [(4, 3, 2, 160), (3, 5, 5, 96), (2, 8, 1, 64), (5, 2, 2, 480)])
+@pytest.mark.parametrize("B,beam,n_best,max_len", [(4, 3, 2, 160), (3, 5, 5, 96), (2, 8, 1, 64), (5, 2, 2, 480),
+                                                   (8, 5, 2, 128),      # 40 rows: two 32-row tiles
+                                                   (32, 5, 1, 96),      # BASELINE config 5: beam 5 x batch 32 = 5 tiles
+                                                   (32, 8, 3, 48)])     # the capacity corner: 256 rows, 8 tiles
 def test_beam_search_vs_oracle(eng, dev, synth_ckpt, B, beam, n_best, max_len):
     """Beam search through the C ABI against oracle/beam.py (whose strategy is pinned on the reference's BeamSearch
     class): hypotheses, their order, scores and the decoder outputs along each hypothesis."""
@@ -531,9 +497,59 @@ def test_device_preprocess_is_bit_identical_to_host_restatement(eng, dev):
     edge = np.full((40, 40, 3), 255, np.uint8); edge[0, 0] = 0; edge[-1, -1] = 254
     pages.append(edge)
     out = eng.preprocess(pages).cpu().numpy()
+    sq = eng.preprocess(pages, pad_to_square=True).cpu().numpy()
     for i, p in enumerate(pages):
         ref = transform_image(p)
         assert np.array_equal(out[i], ref), f"page {i} {p.shape}: {np.abs(out[i] - ref).max()}"
+        ref = transform_image(p, square=True)
+        assert np.array_equal(sq[i], ref), f"page {i} {p.shape} (PadToSquare): {np.abs(sq[i] - ref).max()}"
+
+
+def test_device_crop_box_vs_reference_golden(golden_dir, eng, dev):
+    """The device bounding-box kernel against CropWhite.update_params of the reference's own data_aug.py
+    (tests/golden/crop_pad.json, ragged pages regenerated from their recipe), and the whole device transform with and
+    without PadToSquare against the host restatement whose crop / pad stages are pinned on the same fixture."""
+    from molnextr_amd.preprocess import transform_image
+    with open(os.path.join(golden_dir, "crop_pad.json")) as f:
+        cases = json.load(f)["cases"]
+    pages = [W.synthetic_page(c["case"]) for c in cases]
+    out, crops = eng.preprocess(pages, return_crops=True)
+    crops = crops.cpu().numpy()
+    sq = eng.preprocess(pages, pad_to_square=True).cpu().numpy()
+    out = out.cpu().numpy()
+    for c, page, crop in zip(cases, pages, crops):
+        assert crop.tolist() == c["crop"], (c["case"], crop.tolist(), c["crop"])
+        assert np.array_equal(out[c["case"]], transform_image(page))
+        assert np.array_equal(sq[c["case"]], transform_image(page, square=True))
+
+
+def test_reference_format_checkpoint_loads_through_public_api(dev, tmp_path):
+    """Rehearsal for the day molnextr_best.pth is supplied (BASELINE configs 1 and 4): the synthetic checkpoint written
+    in the reference's training format (DDP 'module.' prefixes, optimizer / scheduler / scaler state, saved args —
+    main.py:389-398) loads through molnextr(model_path=...) and gives the same predictions as the in-memory one; the
+    safetensors conversion of it too."""
+    from molnextr_amd import checkpoint as C
+    from molnextr_amd.model import molnextr
+    ck = W.synthetic_checkpoint(0)
+    pth = {"encoder": {"module." + k: v for k, v in ck["encoder"].items()},
+           "decoder": {"module." + k: v for k, v in ck["decoder"].items()},
+           "optimizer": {"state": {0: {"exp_avg": torch.zeros(4)}}, "param_groups": []}, "scheduler": {"last_epoch": 3},
+           "scaler": {"scale": 65536.0}, "global_step": 1234, "epoch": 7,
+           "args": {"formats": ["chartok_coords", "edges"], "input_size": 384, "coord_bins": 64, "sep_xy": True,
+                    "encoder": "swin_base", "decoder": "transformer"}}
+    src, dst = str(tmp_path / "molnextr_best.pth"), str(tmp_path / "molnextr_best.safetensors")
+    torch.save(pth, src)
+    C.convert(src, dst)
+    pages = [W.synthetic_page(0), W.synthetic_page(5)]
+    outs = []
+    for path in ("synthetic", src, dst):
+        m = molnextr(path, dev, max_batch=4)
+        outs.append(m.predict_images(pages, return_atoms_bonds=True))
+        m.engine.close()
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0][0]["atom_sets"] is not None
+    with pytest.raises(ValueError, match="checkpoint path is required"):
+        molnextr(None, dev)
 
 
 def test_eval_harness_reproduces_reference_batches(eng, dev, tmp_path):

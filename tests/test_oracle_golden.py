@@ -172,3 +172,30 @@ def test_beam_decode_hypotheses_are_ordered_and_grammatical(synth_ckpt):
             assert (seq[:-1] != 2).all()                                   # EOS only as the last id
             prev_x = (seq[:-1] >= 101) & (seq[:-1] < 165)
             assert (seq[1:][prev_x] >= 165).all()                          # grammar mask holds inside the beam
+
+
+def test_oracle_from_pixels_vs_reference_golden(golden_dir, synth_ckpt):
+    """The oracle's composition encoder_forward -> greedy_decode on 6 synthetic images against the reference's own
+    Encoder + Decoder run on the same pixels (pixels_e2e.*): features, every token, every log-prob."""
+    import json
+    from molnextr_amd import weights as W
+    from molnextr_amd.tokenizer import get_tokenizer
+    from oracle.decoder import greedy_decode
+    from oracle.edges import predict_edges
+    from oracle.swin import encoder_forward
+    g = np.load(os.path.join(golden_dir, "pixels_e2e.npz"))
+    with open(os.path.join(golden_dir, "pixels_e2e.json")) as f:
+        preds = json.load(f)["preds"]["m6"]
+    feats = encoder_forward(W.synthetic_images(6), synth_ckpt["encoder"])
+    assert np.abs(feats[:, ::9, ::16].numpy() - g["feat_strided"][:6]).max() < 1e-5
+    out = greedy_decode(feats, synth_ckpt["decoder"])
+    tok = get_tokenizer()["chartok_coords"]
+    for b in range(6):
+        n = int(g["m6_lens"][b])
+        assert out.tokens[b] == g["m6_ids"][b, :n].tolist(), f"row {b}"
+        assert np.abs(np.array(out.token_logp[b]) - g["m6_token_logp"][b, :n]).max() < 1e-4
+        d = tok.sequence_to_smiles(out.tokens[b])
+        assert d["smiles"] == preds[b]["smiles"] and d["indices"] == preds[b]["indices"] and d["coords"] == preds[b]["coords"]
+        if d["indices"]:
+            e, _ = predict_edges(out.hidden[b], d["indices"], synth_ckpt["decoder"])
+            assert np.asarray(e).astype(int).tolist() == preds[b]["edges"], f"row {b}: bonds"

@@ -36,3 +36,42 @@ def test_gray_and_normalise():
     assert x.shape == (3, 384, 384) and x.dtype == np.float32
     np.testing.assert_allclose(x[:, 0, 0], (1.0 - MEAN) / STD, rtol=1e-5)       # white corner
     np.testing.assert_allclose(x.min(axis=(1, 2)), (0.0 - MEAN) / STD, rtol=1e-5, atol=1e-6)
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def test_crop_white_and_pad_to_square_vs_reference_golden(golden_dir):
+    """CropWhite.update_params/apply and PadToSquare.apply of the reference's own data_aug.py (driven by
+    tools/gen_golden.py through a minimal albumentations/cv2 stand-in) on ragged pages: crop parameters, shapes and
+    content hashes. Pages are regenerated from their recipe (W.synthetic_page) and checked by hash first."""
+    import json
+    import os
+    from molnextr_amd import weights as W
+    from molnextr_amd.preprocess import crop_box, pad_to_square
+    with open(os.path.join(golden_dir, "crop_pad.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == len(W.PAGE_CASES)
+    for c in cases:
+        page = W.synthetic_page(c["case"])
+        assert list(page.shape) == c["page_shape"] and _sha(page) == c["page_sha"], "page recipe drifted"
+        assert list(crop_box(page)) == c["crop"], (c["case"], crop_box(page), c["crop"])
+        out = crop_white(page, 50)
+        assert list(out.shape) == c["cropped_shape"] and _sha(out) == c["cropped_sha"], c["case"]
+        sq = pad_to_square(out)
+        assert list(sq.shape) == c["square_shape"] and _sha(sq) == c["square_sha"], c["case"]
+        assert sq.shape[0] == sq.shape[1]
+
+
+def test_pad_to_square_orientation():
+    from molnextr_amd.preprocess import pad_to_square
+    wide = np.zeros((3, 8, 3), np.uint8)
+    sq = pad_to_square(wide)
+    assert sq.shape == (8, 8, 3) and (sq[:2] == 255).all() and (sq[2:5] == 0).all() and (sq[5:] == 255).all()   # 5 // 2 = 2 above
+    tall = np.zeros((9, 2, 3), np.uint8)
+    sq = pad_to_square(tall)
+    assert sq.shape == (9, 9, 3) and (sq[:, :3] == 255).all() and (sq[:, 3:5] == 0).all() and (sq[:, 5:] == 255).all()
+    x = transform_image(np.zeros((30, 90, 3), np.uint8), square=True)
+    assert x.shape == (3, 384, 384)

@@ -21,6 +21,13 @@ Fixtures (all small):
   predict_e2e_conf.json  same with compute_confidence=True on B=3: atom / edge / overall scores
   beam_strategy.npz    BeamSearch.advance/update_finished driven with scripted log-probs: back-pointers, ids, scores,
                        surviving images per step, final n-best predictions
+  pixels_e2e.npz/.json the PATH AS A UNIT (model.py:107-108): Encoder.forward + Decoder.decode of the reference on
+                       W.synthetic_images(32) under synthetic_checkpoint(0) — ids, lengths, token log-probs, first-steps
+                       logits, top-1/top-2 margins of every step, atom positions, bond matrices — for one batch of 6
+                       and one of 32, plus the plain-random decoder (molecule_like=False) cut at 64 steps
+  crop_pad.json        CropWhite.update_params/apply + PadToSquare.apply of the reference's data_aug.py on ragged pages
+
+    python tools/gen_golden.py [name ...]      # only the named groups: swin decoder edges tokenizer e2e beam pixels crop
 """
 import hashlib
 import json
@@ -283,6 +290,105 @@ def gen_beam_strategy():
     np.savez_compressed(os.path.join(GOLD, "beam_strategy.npz"), **out)
 
 
+def _greedy_with_margins(dec, tok, feats, max_length, n_logit_steps=4):
+    """TransformerDecoderAR.decode (greedy) on `feats`, capturing every step's raw logits through a forward hook on the
+    reference's own output_layer. Returns ids / lens / token log-probs as the reference reports them, the raw logits of
+    the first steps, and per (row, step) the top-1 minus top-2 margin of the masked log-probs the strategy saw
+    (log_softmax -> grammar mask -10000 -> EOS ban at step 0), with the argmax cross-checked against the emitted id."""
+    ar = dec.decoder["chartok_coords"]
+    t = tok["chartok_coords"]
+    logits = []
+    h = ar.output_layer.register_forward_hook(lambda m, i, o: logits.append(o.detach().squeeze(1).clone()))
+    with torch.no_grad():
+        preds, scores, token_scores, hidden = ar.decode(feats, 1, 1, max_length=max_length)
+    h.remove()
+    B = feats.shape[0]
+    lens = np.array([len(preds[b][0]) for b in range(B)], dtype=np.int32)
+    T = int(lens.max())
+    ids = np.full((B, T), -1, dtype=np.int32)
+    logp = np.zeros((B, T), dtype=np.float32)
+    margin = np.full((B, T), np.inf, dtype=np.float32)
+    for b in range(B):
+        ids[b, :lens[b]] = preds[b][0].numpy()
+        logp[b, :lens[b]] = np.log(np.array(token_scores[b][0], dtype=np.float64)).astype(np.float32)
+    for s, lg in enumerate(logits):
+        alive = [b for b in range(B) if lens[b] > s]            # compaction keeps the original order
+        assert lg.shape[0] == len(alive), (s, lg.shape, len(alive))
+        lp = torch.log_softmax(lg, dim=-1)
+        prev = [1 if s == 0 else int(ids[b, s - 1]) for b in alive]
+        mask = torch.tensor([t.get_output_mask(p) for p in prev])
+        lp = lp.masked_fill(mask, -10000.0)
+        if s == 0:
+            lp[:, 2] = -1e20
+        top2 = lp.topk(2, dim=-1)
+        for r, b in enumerate(alive):
+            assert int(top2.indices[r, 0]) == int(ids[b, s]), (s, b)
+            margin[b, s] = float(top2.values[r, 0] - top2.values[r, 1])
+    out = {"ids": ids, "lens": lens, "token_logp": logp, "margin": margin}
+    for s in range(min(n_logit_steps, len(logits))):
+        out[f"logits_step{s}"] = logits[s].numpy()
+    return out, preds, hidden
+
+
+def gen_pixels(Encoder, Decoder, args, tok, ck):
+    """The composition the suite never checked in round 1: pixels -> Encoder.forward -> Decoder.decode, run by the
+    reference's own classes. Inputs are W.synthetic_images (pure functions of the image index), weights
+    synthetic_checkpoint(0) (molecule-like decoder) and synthetic_checkpoint(0, molecule_like=False)."""
+    N = 32
+    enc = Encoder(reference_args()).eval()
+    enc.load_state_dict(ck["encoder"], strict=True)
+    img = W.synthetic_images(N)
+    with torch.no_grad():
+        feats = torch.cat([enc(img[i:i + 4])[0] for i in range(0, N, 4)])
+    out = {"feat_strided": feats[:, ::9, ::16].numpy().copy(),
+           "feat_rms": np.array([float(feats.pow(2).mean().sqrt())])}
+    dec = Decoder(args, tok).eval()
+    dec.load_state_dict(ck["decoder"], strict=True)
+    plain = W.synthetic_checkpoint(0, molecule_like=False)
+    dec_p = Decoder(args, tok).eval()
+    dec_p.load_state_dict(plain["decoder"], strict=True)
+    for name, d, B, ml in (("m6", dec, 6, 480), ("m32", dec, 32, 480), ("p6", dec_p, 6, 64), ("p32", dec_p, 32, 64)):
+        o, _, _ = _greedy_with_margins(d, tok, feats[:B], ml)
+        for k, v in o.items():
+            out[f"{name}_{k}"] = v
+        fin = np.isfinite(o["margin"])
+        print(f"pixels {name}: lens {o['lens'].tolist()} margin min {o['margin'][fin].min():.4f} "
+              f"median {np.median(o['margin'][fin]):.3f}")
+    np.savez_compressed(os.path.join(GOLD, "pixels_e2e.npz"), **out)
+    # Decoder.decode end to end (detokenise + bond head) on the batch of 32 and the batch of 6
+    js = {}
+    for name, B in (("m32", 32), ("m6", 6)):
+        with torch.no_grad():
+            preds = dec.decode(feats[:B])
+        js[name] = [{"smiles": p["chartok_coords"]["smiles"], "symbols": p["chartok_coords"]["symbols"],
+                     "coords": p["chartok_coords"]["coords"], "indices": p["chartok_coords"]["indices"],
+                     "edges": p["edges"]} for p in preds]
+    with open(os.path.join(GOLD, "pixels_e2e.json"), "w") as f:
+        json.dump({"images": "W.synthetic_images(32)", "checkpoint": "W.synthetic_checkpoint(0)", "preds": js}, f)
+    print("pixels_e2e: atoms", [len(p["symbols"]) for p in js["m32"]])
+
+
+def gen_crop_pad():
+    """CropWhite(pad=50) and PadToSquare of the reference's own data_aug.py (imported through a minimal
+    albumentations / cv2 stand-in: both classes are pure numpy apart from a constant-border pad) on ragged pages:
+    crop parameters, output shapes and content hashes. Resize / ToGray stay unpinned (OpenCV is not installed)."""
+    from MolNexTR.data_aug import CropWhite, PadToSquare
+    cw, ps = CropWhite(pad=50), PadToSquare()
+    cases = []
+    for i in range(len(W.PAGE_CASES)):
+        page = W.synthetic_page(i)
+        params = cw.update_params({}, image=page)
+        out = cw.apply(page, **{k: v for k, v in params.items() if k.startswith("crop_")})
+        sq = ps.apply(out)
+        cases.append({"case": i, "page_shape": list(page.shape), "page_sha": sha(page),
+                      "crop": [int(params.get(k, 0)) for k in ("crop_top", "crop_bottom", "crop_left", "crop_right")],
+                      "cropped_shape": list(out.shape), "cropped_sha": sha(out),
+                      "square_shape": list(sq.shape), "square_sha": sha(sq)})
+    with open(os.path.join(GOLD, "crop_pad.json"), "w") as f:
+        json.dump({"pages": "W.synthetic_page(case)", "cases": cases}, f, indent=0)
+    print("crop_pad:", [(c["crop"], c["square_shape"][:2]) for c in cases])
+
+
 def main():
     if not have_reference():
         raise SystemExit("/root/reference is not mounted: fixtures can only be regenerated in the build container")
@@ -297,17 +403,29 @@ def main():
     with open(os.path.join(ROOT, "molnextr_amd", "vocab", "vocab_chars.json")) as f:
         assert json.load(f) == tok["chartok_coords"].stoi, "vocab drifted from the reference"
     ck = W.synthetic_checkpoint(0)
-    gen_swin_tiny(Vision_Transformer)
-    gen_swin_full(Encoder, args, ck)
+    want = set(sys.argv[1:]) or {"swin", "decoder", "edges", "tokenizer", "e2e", "beam", "pixels", "crop"}
+    if "swin" in want:
+        gen_swin_tiny(Vision_Transformer)
+        gen_swin_full(Encoder, args, ck)
     args.encoder_dim = 1024
-    dec = gen_decoder(Decoder, args, tok, ck)
-    gen_edges(dec, get_edge_prediction)
-    g = np.load(os.path.join(GOLD, "decoder_greedy.npz"))
-    decoded = [g["ids"][b, :g["lens"][b]].tolist() for b in range(g["ids"].shape[0])]
-    gen_tokenizer(tok, decoded)
-    gen_e2e(dec, W.hash_normal("e2e_features", (4, 144, 1024), 0.5))
-    gen_e2e_confidence(dec, W.hash_normal("conf_features", (3, 144, 1024), 0.5))
-    gen_beam_strategy()
+    dec = None
+    if want & {"decoder", "edges", "e2e"}:
+        dec = gen_decoder(Decoder, args, tok, ck)           # (cheap; also the model the next groups run)
+    if "edges" in want:
+        gen_edges(dec, get_edge_prediction)
+    if "tokenizer" in want:
+        g = np.load(os.path.join(GOLD, "decoder_greedy.npz"))
+        decoded = [g["ids"][b, :g["lens"][b]].tolist() for b in range(g["ids"].shape[0])]
+        gen_tokenizer(tok, decoded)
+    if "e2e" in want:
+        gen_e2e(dec, W.hash_normal("e2e_features", (4, 144, 1024), 0.5))
+        gen_e2e_confidence(dec, W.hash_normal("conf_features", (3, 144, 1024), 0.5))
+    if "beam" in want:
+        gen_beam_strategy()
+    if "pixels" in want:
+        gen_pixels(Encoder, Decoder, args, tok, ck)
+    if "crop" in want:
+        gen_crop_pad()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}
     print("fixture bytes:", sizes, "total", sum(sizes.values()))
 

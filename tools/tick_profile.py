@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-tick view of a rocprofv3 rocpd database of a bench run: a decode tick starts with dec_begin_kernel; for every
+tick, its wall time (start of this begin -> start of the next one on the same stream), the sum of its kernels'
+durations, its launch count and the row capacity it was launched for (grid of the first skinny linear). Grouped by
+capacity: how long a tick takes when few rows are alive (the drain tail) vs many.   usage: tick_profile.py db [out]"""
+import sqlite3
+import statistics
+import sys
+from collections import defaultdict
+
+
+def main(path, out=None):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    q = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else "0")
+    rows = c.execute(f"select name, start, end, grid_x, grid_y, workgroup_x, workgroup_y, {q} from kernels order by start").fetchall()
+    ticks = []
+    cur = None
+    for name, st, en, gx, gy, wx, wy, sid in rows:
+        if "dec_begin_kernel" in name or "beam_begin_kernel" in name:
+            if cur:
+                ticks.append(cur)
+            cur = {"start": st, "sid": sid, "kern": 0.0, "n": 0, "cap": None, "last_end": en}
+        if cur is None or sid != cur["sid"]:
+            continue
+        if not ("dec_" in name or "beam_" in name):
+            continue
+        cur["kern"] += en - st
+        cur["n"] += 1
+        cur["last_end"] = max(cur["last_end"], en)
+        if cur["cap"] is None and "dec_linear" in name:
+            cur["cap"] = (gy // max(wy, 1)) * 32
+    if cur:
+        ticks.append(cur)
+    by = defaultdict(list)
+    for a, b in zip(ticks, ticks[1:]):
+        wall = b["start"] - a["start"]
+        if wall < 5e6:                      # back-to-back ticks only (skip host gaps)
+            by[a["cap"]].append((wall / 1e3, a["kern"] / 1e3, a["n"], (a["last_end"] - a["start"]) / 1e3))
+    lines = [f"{'rows_cap':>8s} {'ticks':>6s} {'wall_us_med':>11s} {'wall_us_p10':>11s} {'busy_us_med':>11s} {'span_us_med':>11s} {'launches':>8s}"]
+    for cap in sorted(k for k in by if k is not None):
+        v = by[cap]
+        w = sorted(x[0] for x in v)
+        lines.append(f"{cap:8d} {len(v):6d} {statistics.median(w):11.1f} {w[len(w) // 10]:11.1f} "
+                     f"{statistics.median(x[1] for x in v):11.1f} {statistics.median(x[3] for x in v):11.1f} {v[0][2]:8d}")
+    txt = "\n".join(lines)
+    print(txt)
+    if out:
+        open(out, "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
