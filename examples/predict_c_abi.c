@@ -42,7 +42,8 @@ int run(const mnx_weight_desc* weights, int n_weights, const float* host_images 
     hipMemcpy(images, host_images, n_images * img_elems * sizeof(float), 1 /* hipMemcpyHostToDevice */);
 
     /* reference batches of 16 images, as `predict_images(batch_size=16)` numbers them (MolNexTR/model.py:97) */
-    int rc = mnx_predict(eng, images, n_images, /*ref_batch=*/16, /*max_len=*/480, tokens, lengths, n_atoms, atom_idx,
+    int rc = mnx_predict(eng, images, n_images, /*ref_batch=*/16, /*max_len=*/480, /*stop_on_eos=*/1, tokens, lengths, n_atoms,
+                         atom_idx,
                          edges, /*kmax=*/160, /*stream=*/NULL);
     if (rc != MNX_OK) fprintf(stderr, "mnx_predict: %s\n", mnx_last_error(eng));
     /* ... copy tokens / lengths / atom_idx / edges back and detokenise (tokenization.py:464-515) ... */

@@ -186,12 +186,13 @@ int mnx_atom_scan(mnx_engine* h, const int32_t* tokens, const int32_t* lengths, 
  * Up to cfg.dec_slots sequences (dec_slots / 32 reference batches; 2048 by default) are resident on the GPU at once;
  * every decode tick advances all of them by one token, finished batches are retired (atom positions + bond head run on device) and the freed rows are
  * refilled with the next batch while the encoder of the following batch runs on a second stream.
+ *   stop_on_eos 1 = reference behaviour; 0 = every sequence runs to max_len (bench aid: deterministic decode work)
  *   tokens    device int32 [n_img,max_len]; lengths device int32 [n_img]
  *   n_atoms   device int32 [n_img]; atom_idx device int32 [n_img,kmax]; edges device uint8 [n_img,kmax,kmax]
  * Synchronous with respect to its outputs. */
 int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t max_len,
-                int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx, uint8_t* edges,
-                int32_t kmax, void* stream);
+                int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx,
+                uint8_t* edges, int32_t kmax, void* stream);
 
 /* Kernel-level timing aid for bench.py: runs the 16-bit MFMA GEMM of the encoder on caller buffers.
  * C[M,N] = A[M,K] . W[N,K]^T + bias, A/W 16-bit device, epi: 0 bias->16-bit, 1 bias+GELU->16-bit,
@@ -199,13 +200,27 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
 int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C, const float* bias, int32_t M,
                int32_t N, int32_t K, void* stream);
 
-/* Measurement aid for bench.py: while enabled, mnx_encode brackets every MFMA GEMM launch with a pair of HIP
- * events recorded on the stream the kernel is launched on (also inside mnx_predict, i.e. live in a timed region).
- * `enable` = n > 0: every n-th mnx_encode call since the enable is bracketed, at most 16 calls (the event pool stays
- * small and is reused). mnx_profile_read synchronises, returns the totals accumulated since the last read (summed
- * event-to-event milliseconds, algorithmic FLOP = 2*M*N*K per launch, launch count) and resets them. */
+/* Measurement aid for bench.py: while enabled, mnx_encode brackets every kernel launch of the sampled calls with a
+ * pair of HIP events recorded on the stream the kernel is launched on (also inside mnx_predict, i.e. live in a timed
+ * region). `enable` = n > 0: every n-th mnx_encode call since the enable is sampled, at most 4 calls (the event pool
+ * stays small and is reused; the launches of the other calls run un-bracketed). mnx_profile_read synchronises and
+ * returns, for one kernel class, the totals accumulated since the last reset: summed event-to-event milliseconds,
+ * algorithmic work and launch count.
+ *   kind 0  MFMA GEMM             work = FLOP (2*M*N*K per launch)
+ *   kind 1  LayerNorm             work = HBM bytes (fp32 in, operand-type out [+ fp32 out])
+ *   kind 2  window attention      work = HBM bytes (qkv in, context out)
+ *   kind 3  patch embedding       work = HBM bytes (image in, fp32 tokens out)
+ *   kind < 0  reset the pool */
 int mnx_profile_enable(mnx_engine* h, int32_t enable);
-int mnx_profile_read(mnx_engine* h, double* gemm_ms, double* gemm_flop, int64_t* gemm_launches);
+int mnx_profile_read(mnx_engine* h, int32_t kind, double* ms, double* work, int64_t* launches);
+
+/* Measurement aid: the two per-row attention kernels of a decode tick (self block: attention over the cache +
+ * final_linear + LayerNorm + context query; cross block: attention over the projected memory + final_linear +
+ * LayerNorm) launched `iters` times each between HIP events with `rows` sequences resident at position t. Isolated
+ * (nothing else runs), so the algorithmic HBM bytes per launch are known exactly: rows*8*(t+1)*256 B (self K+V) and
+ * rows*8*144*256 B (cross K+V). Overwrites the decoder state: not to be called while a decode call is in flight. */
+int mnx_probe_decode_attn(mnx_engine* h, int32_t rows, int32_t t, int32_t iters, double* self_ms, double* cross_ms,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,8 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
 hipError_t beam_enqueue_init(const DecBuffers& b, const BeamBuffers& bm, int max_len, hipStream_t s);
 hipError_t beam_enqueue_gather(const DecBuffers& b, const BeamBuffers& bm, int out_len, int* o_tokens, int* o_len,
                                float* o_scores, float* o_hidden, hipStream_t s);
+hipError_t dec_probe_attn(const DecWeights& w, const DecBuffers& b, int rows, int t, int iters, hipEvent_t* ev,
+                          hipStream_t s);
 hipError_t dec_enqueue_admit_rows(const DecBuffers& b, const int* chunk_ids_dev, int n, int max_len, int stop_on_eos,
                                   hipStream_t s);
 hipError_t gather_enqueue(const DecBuffers& b, const int* slots_dev, int n_rows, int out_len, int* o_tokens, int* o_len,

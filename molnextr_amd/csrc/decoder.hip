@@ -69,76 +69,11 @@ __global__ __launch_bounds__(256) void sgemm_tn_kernel(const float* __restrict__
     }
 }
 
-// The same contraction on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains): 64x64 tile, 4 waves of
-// 32x32, operands from global memory straight into the fragment layout (lane (fr, fg): float4 at [row fr][k + 4 fg],
-// the k-slot permutation is the same on both operands), 4 K-chunks of 16 in flight. Used for the per-image work of an
-// admission (enc_transform 4608x256x1024, cross-attention K/V 4608x3072x256). Parity-identical in the GPU tests; end to
-// end it measured within noise of the VALU kernel (the admission work is 1.6 % of the kernel time), so it stays behind
-// MNX_SGEMM_MFMA.
-__global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                         const float* __restrict__ bias, float* __restrict__ C, int M,
-                                                         int N, int K, int perm_S) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.y * 64 + (wave & 1) * 32, n0 = blockIdx.x * 64 + (wave >> 1) * 32;
-    const float* ap[2];
-    const float* wp[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        ap[t] = A + (size_t)min(m0 + t * 16 + fr, M - 1) * K + fg * 4;
-        wp[t] = W + (size_t)min(n0 + t * 16 + fr, N - 1) * K + fg * 4;
-    }
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 64) {           // K % 64 == 0
-        f32x4 a[2][4], w[2][4];
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t][kc] = *(const f32x4*)(ap[t] + k0 + 16 * kc);
-                w[t][kc] = *(const f32x4*)(wp[t] + k0 + 16 * kc);
-            }
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][kc][j], w[0][kc][j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][kc][j], w[1][kc][j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][kc][j], w[0][kc][j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][kc][j], w[1][kc][j], acc[1][1], 0, 0, 0);
-            }
-    }
-    // D layout: lane holds rows fg*4 + r (r = 0..3) of column fr
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + nt * 16 + fr;
-            if (n >= N) continue;
-            const float b = bias ? bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + mt * 16 + fg * 4 + r;
-                if (m >= M) continue;
-                const size_t off = perm_S > 0 ? ((((size_t)(m / perm_S) * (N >> 8) + (n >> 8)) * 8 + ((n & 255) >> 5)) * perm_S +
-                                                 (m % perm_S)) * 32 + (n & 31)
-                                              : (size_t)m * N + n;
-                C[off] = acc[mt][nt][r] + b;
-            }
-        }
-}
-
 hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                            hipStream_t s, int perm_S) {
     if ((K & 15) || (N & 3) || (perm_S > 0 && ((N & 255) || M % perm_S))) return hipErrorInvalidValue;
-    static const bool valu = getenv("MNX_SGEMM_MFMA") == nullptr;     // A/B knob: MFMA form (parity-identical, no end-to-end gain)
     dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-    if (!valu && (K & 63) == 0 && M >= 1024)
-        hipLaunchKernelGGL(sgemm_mfma_kernel, grid, block, 0, s, A, W, bias, C, M, N, K, perm_S);
-    else
-        hipLaunchKernelGGL(sgemm_tn_kernel, grid, block, 0, s, A, W, bias, C, M, N, K, perm_S);
+    hipLaunchKernelGGL(sgemm_tn_kernel, grid, block, 0, s, A, W, bias, C, M, N, K, perm_S);
     return hipGetLastError();
 }
 
@@ -305,157 +240,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     }
 }
 
-// Second form of the skinny linear: same tile (32 active rows x 32 output columns, K split over the 4 waves, fp32 MFMA
-// 16x16x4) but the operands go from global memory STRAIGHT into the MFMA register layout — lane (fr, fg) of wave w
-// loads the float4 at [row fr][64 w + 16 kc + 4 fg], which is exactly the fragment the staged form read back from LDS.
-// No LDS staging pass and 17 KB of LDS instead of 66 KB (only the cross-wave reduction and the LayerNorm partial sums
-// go through LDS), so these latency-bound workgroups fit next to two resident encoder GEMM workgroups on a CU.
-// Measured: parity-identical, but 0.8 % SLOWER end to end than the staged form (2743 vs 2765 molecules/s, A/B/A/B):
-// the 64-byte row segments of the fragment loads cost more than the LDS pass saves. Kept behind MNX_DEC_LINEAR_DIRECT.
-// LayerNorm: two-pass, the row statistics are combined over the 4 lane groups (shuffles) and the 4 waves (LDS).
-template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void dec_linear_direct_kernel(LinArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
-    __shared__ float s_part[4][32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * TN;
-    const int row0 = blockIdx.y * ROW_TILE;
-    const int n_act = a.st->n_active;
-    if (row0 >= n_act) return;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int kq = wave * 64 + fg * 4;               // this lane's k offset inside a 256-wide K chunk (+ 16 kc)
-    bool live[2];
-    int slot_[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        live[rt] = row0 + rt * 16 + fr < n_act;
-        slot_[rt] = live[rt] ? a.st->active[row0 + rt * 16 + fr] : 0;
-    }
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < a.K; k0 += 256) {
-        f32x4 xa[2][4], wb[2][4];
-        // ---- all loads of the chunk in flight at once ----
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const float* wsrc = a.W + (size_t)(n0 + ct * 16 + fr) * a.K + k0 + kq;
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) wb[ct][kc] = *(const f32x4*)(wsrc + 16 * kc);
-        }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            if (PRO == 2) {
-                // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
-                const float* e = a.emb + (size_t)a.st->prev_tok[slot_[rt]] * 256 + kq;
-                const float* p = a.pe + (size_t)a.st->rank[slot_[rt]] * 256 + kq;
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc)
-                    xa[rt][kc] = live[rt] ? *(const f32x4*)(e + 16 * kc) * 16.0f + *(const f32x4*)(p + 16 * kc) : zero4;
-            } else {
-                const float* src = a.in + (size_t)(row0 + rt * 16 + fr) * a.K + k0 + kq;
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) xa[rt][kc] = live[rt] ? *(const f32x4*)(src + 16 * kc) : zero4;
-            }
-        }
-        if (PRO == 2 && blockIdx.x == 0) {           // residual stream x = embedding, written once per row
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                if (live[rt]) {
-                    float* dst = a.x_write + (size_t)(row0 + rt * 16 + fr) * 256 + kq;
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) *(f32x4*)(dst + 16 * kc) = xa[rt][kc];
-                }
-        }
-        if (PRO != 0) {                              // LayerNorm over the 256-wide row (K == 256), eps 1e-6
-            float mean[2], rstd[2];
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) {
-                        if (pass == 1) xa[rt][kc] -= mean[rt];
-                        const f32x4 v = xa[rt][kc];
-                        s += pass == 0 ? (v[0] + v[1]) + (v[2] + v[3]) : (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                    }
-                    s += __shfl_xor(s, 16, 64);
-                    s += __shfl_xor(s, 32, 64);
-                    if (fg == 0) s_part[wave][rt * 16 + fr] = s;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const int r = rt * 16 + fr;
-                    const float t = (s_part[0][r] + s_part[1][r]) + (s_part[2][r] + s_part[3][r]);
-                    if (pass == 0) mean[rt] = t * (1.0f / 256.0f);
-                    else rstd[rt] = rsqrtf(t * (1.0f / 256.0f) + 1e-6f);
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const f32x4 g = *(const f32x4*)(a.gamma + kq + 16 * kc), b = *(const f32x4*)(a.beta + kq + 16 * kc);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) xa[rt][kc] = xa[rt][kc] * rstd[rt] * g + b;
-            }
-        }
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][kc][j], wb[0][kc][j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][kc][j], wb[1][kc][j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][kc][j], wb[0][kc][j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][kc][j], wb[1][kc][j], acc[1][1], 0, 0, 0);
-            }
-    }
-    // cross-wave reduction through LDS: red[wave][row][col], D layout: lane holds rows fg*4+r, column fr
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                red[(wave * 32 + mt * 16 + fg * 4 + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
-    __syncthreads();
-    const int lrow = tid >> 3, part = tid & 7;       // epilogue mapping: 8 threads per row, 4 columns each
-    if (row0 + lrow >= n_act) return;
-    const int slot = a.st->active[row0 + lrow];
-    const int row = row0 + lrow;
-    const int nc = part * 4;
-    f32x4 v;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        v[u] = (red[(0 * 32 + lrow) * 33 + nc + u] + red[(1 * 32 + lrow) * 33 + nc + u]) +
-               (red[(2 * 32 + lrow) * 33 + nc + u] + red[(3 * 32 + lrow) * 33 + nc + u]);
-    const int n = n0 + nc;
-    v += *(const f32x4*)(a.bias + n);
-    if (EPI == 0) {
-        const int part_ = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
-        if (part_ == 0) {
-            *(f32x4*)(a.out + (size_t)row * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
-        } else {
-            float* cache = part_ == 1 ? a.kcache : a.vcache;
-            *(f32x4*)(cache + (((size_t)slot * a.heads + hd) * a.T + a.st->t[slot]) * 32 + d) = v;
-        }
-    } else if (EPI == 1) {
-        float* o = a.out + (size_t)row * a.N + n;
-        *(f32x4*)o = *(const f32x4*)o + v;
-    } else if (EPI == 2) {
-        *(f32x4*)(a.out + (size_t)row * a.N + n) = v * 0.17677669529663687f;
-    } else {
-        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-        *(f32x4*)(a.out + (size_t)row * a.N + n) = v;
-    }
-}
-
 // =============================================================================================
-// Single-query attention, one wave per (slot, head): softmax(q.K^T) . V (fp32 throughout, as onmt:
+// Single-query attention, 4 waves per (sequence, head): softmax(q.K^T) . V (fp32 throughout, as onmt:
 // scores.float(), no mask for a single query position). Self: keys 0..t[slot] of the slot's cache (32 floats
-// apart). Cross: the 144 projected memory rows of the slot's memory block (`kstride` floats apart).
+// apart). Cross: the 144 projected memory rows of the slot's memory block.
+// (A per-sequence form that fuses attention + final_linear + LayerNorm + next query into one workgroup per row —
+//  3 launches per layer instead of 6 — was built and measured in round 2: slower at every row count, because one
+//  workgroup then streams 256-512 KB of fp32 weights through one CU)
 // =============================================================================================
 struct AttnArgs {
     const float* q;      // [slots, 256] pre-scaled
@@ -720,9 +511,7 @@ __global__ void dec_admit_kernel(DecState* st, const int* slots, const int* rowc
 // ---- host-side enqueue helpers (engine.hip captures the tick into a hipGraph) -----------------
 template <int PRO, int EPI>
 static void lin(hipStream_t s, const LinArgs& a, int slots) {
-    static const bool staged = getenv("MNX_DEC_LINEAR_DIRECT") == nullptr;   // A/B knob: the LDS-free form (-0.8 %)
-    if (staged) hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dec_linear_direct_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
 }
 
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s) {
@@ -778,16 +567,17 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         // LN2 -> context query
         a.in = b.x; a.W = L.wq2; a.bias = L.bq2; a.gamma = L.ln2_g; a.beta = L.ln2_b; a.out = b.q;
         lin<1, 2>(s, a, slots);
+        at.anc = nullptr;
         at.K = b.mem_kv + (size_t)l * 2 * b.S * D;    // memory K/V: [block][layer][K|V][head][s][32]
         at.V = at.K + (size_t)b.S * D;
         at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = (long long)b.S * 32; at.kstride = 32;
         at.fixed_keys = b.S; at.cross = 1;
         hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(slots * H), dim3(256), 0, s, at);
         // context final_linear + residual
-        a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = b.x;
+        a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = b.x; a.N = D; a.K = D;
         lin<0, 1>(s, a, slots);
         // feed-forward: LN -> w_1 -> GELU -> w_2 -> + residual
-        a.in = b.x; a.W = L.w1; a.bias = L.b1; a.gamma = L.lnf_g; a.beta = L.lnf_b; a.out = b.h; a.N = w.dff;
+        a.in = b.x; a.W = L.w1; a.bias = L.b1; a.gamma = L.lnf_g; a.beta = L.lnf_b; a.out = b.h; a.N = w.dff; a.K = D;
         lin<1, 3>(s, a, slots);
         a.in = b.h; a.W = L.w2; a.bias = L.b2; a.out = b.x; a.N = D; a.K = w.dff;
         lin<0, 1>(s, a, slots);
@@ -970,6 +760,44 @@ hipError_t edges_enqueue(const DecWeights& w, const DecBuffers& bf, const float*
     hipLaunchKernelGGL(edge_sym_kernel, dim3((kmax + 63) / 64, kmax, B), dim3(64), 0, s, bf.edge_prob, n_atoms, edges,
                        scores, kmax);
     return hipGetLastError();
+}
+
+}  // namespace mnx
+
+namespace mnx {
+
+// ---- measurement aid (mnx_probe_decode_attn): `rows` sequences resident at position t, then the self- and the cross-
+// attention kernel of layer 0 launched `iters` times each between HIP events (isolated: algorithmic HBM bytes are known exactly)
+__global__ void dec_probe_state_kernel(DecState* st, int rows, int t, int max_len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) {
+        st->alive[i] = 1; st->t[i] = t; st->prev_tok[i] = 5; st->len[i] = t; st->chunk[i] = (i >> 5) & (MAX_CHUNKS - 1);
+        st->rowc[i] = i & 31; st->rank[i] = i & 31; st->mem_blk[i] = i; st->max_len[i] = max_len; st->stop_on_eos[i] = 0;
+    }
+}
+
+hipError_t dec_probe_attn(const DecWeights& w, const DecBuffers& b, int rows, int t, int iters, hipEvent_t* ev,
+                          hipStream_t s) {
+    const int D = 256, H = w.heads, T = b.T;
+    const int cap = (rows + ROW_TILE - 1) / ROW_TILE * ROW_TILE;
+    hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st);
+    hipLaunchKernelGGL(dec_probe_state_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, b.st, rows, t, T);
+    hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, cap);
+    AttnArgs at = {};
+    at.q = b.q; at.K = b.self_k; at.V = b.self_v; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
+    at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32;
+    hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);      // warm-up
+    hipError_t e = hipEventRecord(ev[0], s);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);
+    if (e == hipSuccess) e = hipEventRecord(ev[1], s);
+    at.K = b.mem_kv; at.V = at.K + (size_t)b.S * D;
+    at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = (long long)b.S * 32; at.fixed_keys = b.S; at.cross = 1;
+    hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);      // warm-up
+    if (e == hipSuccess) e = hipEventRecord(ev[2], s);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);
+    if (e == hipSuccess) e = hipEventRecord(ev[3], s);
+    hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 }  // namespace mnx

@@ -77,7 +77,8 @@ struct mnx_engine {
     int prof_stride = 1;       // bracket the GEMMs of every prof_stride-th mnx_encode call ...
     int prof_calls = 0;        // ... counted since mnx_profile_enable
     int prof_groups = 0;       // encode calls bracketed so far (capped: the event pool stays small)
-    struct Ev { hipEvent_t a, b; double flop; };
+    int prof_max_groups = 4;
+    struct Ev { hipEvent_t a, b; double work; int kind; };   // kind 0 GEMM (work = FLOP), 1 LayerNorm, 2 window attention, 3 patch embed (work = algorithmic HBM bytes)
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
 };
@@ -535,11 +536,11 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         return e;
     };
     // sampled measurement: every prof_stride-th encode call, at most 16 calls per enable
-    const bool bracket = h->profiling && (h->prof_calls++ % h->prof_stride) == 0 && h->prof_groups < 16;
+    const bool bracket = h->profiling && (h->prof_calls++ % h->prof_stride) == 0 && h->prof_groups < h->prof_max_groups;
     if (bracket) ++h->prof_groups;
-    auto gemm = [&](int epi, const void* A, const void* Wt, void* Cc, const float* bias, const float* resid, int M,
-                    int N, int K) -> hipError_t {
-        if (!bracket) return launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s);
+    // brackets one launch with a pair of HIP events on the stream it is launched on (sampled encode calls only)
+    auto timed = [&](int kind, double work, auto&& launch) -> hipError_t {
+        if (!bracket) return launch();
         if (h->ev_used == h->ev_pool.size()) {
             mnx_engine::Ev ev{};
             hipError_t e1 = hipEventCreate(&ev.a), e2 = hipEventCreate(&ev.b);
@@ -547,14 +548,25 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
             h->ev_pool.push_back(ev);
         }
         mnx_engine::Ev& ev = h->ev_pool[h->ev_used++];
-        ev.flop = 2.0 * (double)M * (double)N * (double)K;
+        ev.work = work; ev.kind = kind;
         hipError_t e0 = hipEventRecord(ev.a, s);
         if (e0 != hipSuccess) return e0;
-        e0 = launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s);
+        e0 = launch();
         if (e0 != hipSuccess) return e0;
         return hipEventRecord(ev.b, s);
     };
-    HIPCHK(h, launch_patch_embed(images, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta, cur, B, c.img_size, C, s));
+    const double es = (double)dt_size(dt);
+    auto gemm = [&](int epi, const void* A, const void* Wt, void* Cc, const float* bias, const float* resid, int M,
+                    int N, int K) -> hipError_t {
+        return timed(0, 2.0 * (double)M * (double)N * (double)K,
+                     [&]() { return launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s); });
+    };
+    auto ln = [&](const float* x, const float* g, const float* b, void* y16, float* y32, int M, int Cc) -> hipError_t {
+        return timed(1, (double)M * Cc * (4.0 + (y16 ? es : 0.0) + (y32 ? 4.0 : 0.0)),
+                     [&]() { return launch_layernorm16(dt, x, g, b, y16, y32, M, Cc, 1e-5f, s); });
+    };
+    HIPCHK(h, timed(3, (double)B * (3.0 * c.img_size * c.img_size + (double)Hh * Ww * C) * 4.0,
+                    [&]() { return launch_patch_embed(images, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta, cur, B, c.img_size, C, s); }));
     HIPCHK(h, tap((size_t)B * Hh * Ww * C));
     for (int si = 0; si < c.n_stages; ++si) {
         StageW& st = h->stages[si];
@@ -562,11 +574,12 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
             const BlockW& w = st.blocks[bi];
             const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
-            HIPCHK(h, launch_layernorm16(dt, cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C, 1e-5f, s));
+            HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C));
             HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, w.qkv_w, h->qkv16, w.qkv_b, nullptr, M, 3 * C, C));
-            HIPCHK(h, launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s));
+            HIPCHK(h, timed(2, (double)M * C * 4.0 * es,
+                            [&]() { return launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s); }));
             HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, w.proj_w, cur, w.proj_b, cur, M, C, C));
-            HIPCHK(h, launch_layernorm16(dt, cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C, 1e-5f, s));
+            HIPCHK(h, ln(cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C));
             HIPCHK(h, gemm(EPI_GELU_16, h->xn16, w.fc1_w, h->h16, w.fc1_b, nullptr, M, 4 * C, C));
             HIPCHK(h, gemm(EPI_RESID_F32, h->h16, w.fc2_w, cur, w.fc2_b, cur, M, C, 4 * C));
             HIPCHK(h, tap((size_t)M * C));
@@ -579,7 +592,7 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
             HIPCHK(h, tap((size_t)B * Hh * Ww * C));
         }
     }
-    HIPCHK(h, launch_layernorm16(dt, cur, h->fn_g, h->fn_b, nullptr, features_out, B * Hh * Ww, C, 1e-5f, s));
+    HIPCHK(h, ln(cur, h->fn_g, h->fn_b, nullptr, features_out, B * Hh * Ww, C));
     return MNX_OK;
 }
 
@@ -798,8 +811,8 @@ int mnx_atom_scan(mnx_engine* h, const int32_t* tokens, const int32_t* lengths, 
 
 // The whole hot path for n_img images with continuous batching (see include/molnextr_hip.h).
 int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t max_len,
-                int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx, uint8_t* edges,
-                int32_t kmax, void* stream) {
+                int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx,
+                uint8_t* edges, int32_t kmax, void* stream) {
     if (!h) return MNX_ERR_INVALID_ARG;
     if (!images || !tokens || !lengths || !n_atoms || !atom_idx || !edges || n_img < 1) {
         h->err = "mnx_predict: null/empty argument";
@@ -900,7 +913,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             int* sl_pin = pin_slots + (size_t)ck.tag * ROW_TILE;     // pinned, private to this tag until it retires
             for (int i = 0; i < n; ++i) sl_pin[i] = ck.slots[i];
             HIPCHK(h, hipMemcpyAsync(sl_dev, sl_pin, (size_t)n * 4, hipMemcpyHostToDevice, s));
-            HIPCHK(h, dec_enqueue_admit(h->db, sl_dev, nullptr, n, ck.tag, ck.tag * ROW_TILE, max_len, 1, s));
+            HIPCHK(h, dec_enqueue_admit(h->db, sl_dev, nullptr, n, ck.tag, ck.tag * ROW_TILE, max_len, stop_on_eos ? 1 : 0, s));
             bound += n;
             admits.emplace_back(seq, n);
             live.push_back(std::move(ck));
@@ -972,21 +985,43 @@ int mnx_profile_enable(mnx_engine* h, int32_t enable) {
     return MNX_OK;
 }
 
-int mnx_profile_read(mnx_engine* h, double* gemm_ms, double* gemm_flop, int64_t* gemm_launches) {
+int mnx_profile_read(mnx_engine* h, int32_t kind, double* ms_out, double* work_out, int64_t* launches_out) {
     if (!h) return MNX_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    double ms = 0.0, flop = 0.0;
+    double ms = 0.0, work = 0.0;
+    int64_t n = 0;
     for (size_t i = 0; i < h->ev_used; ++i) {
+        if (h->ev_pool[i].kind != kind) continue;
         float t = 0.f;
         HIPCHK(h, hipEventSynchronize(h->ev_pool[i].b));
         HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[i].a, h->ev_pool[i].b));
         ms += t;
-        flop += h->ev_pool[i].flop;
+        work += h->ev_pool[i].work;
+        ++n;
     }
-    if (gemm_ms) *gemm_ms = ms;
-    if (gemm_flop) *gemm_flop = flop;
-    if (gemm_launches) *gemm_launches = (int64_t)h->ev_used;
-    h->ev_used = 0;
+    if (ms_out) *ms_out = ms;
+    if (work_out) *work_out = work;
+    if (launches_out) *launches_out = n;
+    if (kind < 0) h->ev_used = 0;       // kind < 0: reset the pool (after the per-kind reads)
+    return MNX_OK;
+}
+
+int mnx_probe_decode_attn(mnx_engine* h, int32_t rows, int32_t t, int32_t iters, double* self_ms, double* cross_ms,
+                          void* stream) {
+    if (!h || rows < 1 || rows > h->db.slots || t < 0 || t >= h->db.T || iters < 1) return MNX_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+    hipError_t err = dec_probe_attn(h->dw, h->db, rows, t, iters, ev, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    float a = 0.f, b = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&a, ev[0], ev[1]);
+    if (err == hipSuccess) err = hipEventElapsedTime(&b, ev[2], ev[3]);
+    for (auto& e : ev) hipEventDestroy(e);
+    if (err != hipSuccess) { h->err = std::string("mnx_probe_decode_attn: ") + hipGetErrorString(err); return MNX_ERR_HIP; }
+    if (self_ms) *self_ms = (double)a / iters;
+    if (cross_ms) *cross_ms = (double)b / iters;
     return MNX_OK;
 }
 

@@ -100,7 +100,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
                                                       const float* resid, int M, int N, int K, int tiles_n,
                                                       int n_tiles) {
     typedef typename H16<T>::v8 v8;
-    typedef typename H16<T>::v4 v4;
     constexpr int NT = BN / 32;          // 16-wide n-tiles per wave (waves are 2(M) x 2(N))
     constexpr int WLD = BN / 32;         // W chunks per thread per K-tile
     constexpr int STG = (BM + BN) * BK * 2;   // bytes per stage
@@ -275,7 +274,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     f32x4 acc[2][2];   // [nt][mt]
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
     for (int k0 = 0; k0 < K; k0 += 16) {           // K % 16 == 0
         f32x4 a[2], w[2];
 #pragma unroll

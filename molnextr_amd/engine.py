@@ -21,7 +21,8 @@ _lib = None
 ABI_VERSION = 3
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
-           "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess")
+           "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess",
+           "mnx_probe_decode_attn")
 
 
 class MnxConfig(C.Structure):
@@ -78,7 +79,9 @@ def load_library():
     lib.mnx_profile_enable.restype = C.c_int
     lib.mnx_profile_enable.argtypes = [vp, i32]
     lib.mnx_profile_read.restype = C.c_int
-    lib.mnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.mnx_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.mnx_probe_decode_attn.restype = C.c_int
+    lib.mnx_probe_decode_attn.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     lib.mnx_set_token_classes.restype = C.c_int
     lib.mnx_set_token_classes.argtypes = [vp, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     lib.mnx_atom_scan.restype = C.c_int
@@ -88,7 +91,7 @@ def load_library():
     lib.mnx_decode_beam.restype = C.c_int
     lib.mnx_decode_beam.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.mnx_predict.restype = C.c_int
-    lib.mnx_predict.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
+    lib.mnx_predict.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
     if lib.mnx_abi_version() != ABI_VERSION:
         raise ImportError(f"libmolnextr_hip.so ABI {lib.mnx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
     _lib = lib
@@ -278,7 +281,8 @@ class Engine:
         return edges, scores
 
     # -- whole path, continuous batching ----------------------------------------------------------
-    def predict(self, images: torch.Tensor, ref_batch: int = 32, max_len: Optional[int] = None) -> dict:
+    def predict(self, images: torch.Tensor, ref_batch: int = 32, max_len: Optional[int] = None,
+                stop_on_eos: bool = True) -> dict:
         """Encoder + greedy decode + atom positions + bond head for all images (mnx_predict)."""
         assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
         n = images.shape[0]
@@ -289,7 +293,7 @@ class Engine:
         n_atoms = torch.empty(n, dtype=torch.int32, device=dev)
         atom_idx = torch.zeros(n, k, dtype=torch.int32, device=dev)
         edges = torch.zeros(n, k, k, dtype=torch.uint8, device=dev)
-        rc = self.lib.mnx_predict(self.h, _ptr(images), n, ref_batch, max_len, _ptr(tokens), _ptr(lengths),
+        rc = self.lib.mnx_predict(self.h, _ptr(images), n, ref_batch, max_len, int(stop_on_eos), _ptr(tokens), _ptr(lengths),
                                   _ptr(n_atoms), _ptr(atom_idx), _ptr(edges), k, _stream())
         self._check(rc, "mnx_predict")
         return {"tokens": tokens, "lengths": lengths, "n_atoms": n_atoms, "atom_idx": atom_idx, "edges": edges}
@@ -308,11 +312,29 @@ class Engine:
         """True / n: bracket the GEMMs of every n-th encode call with HIP events (at most 16 calls); False: off."""
         self._check(self.lib.mnx_profile_enable(self.h, int(enable)), "mnx_profile_enable")
 
-    def profile_read(self):
-        """(gemm_ms, gemm_flop, launches) accumulated by HIP events since the last read."""
-        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-        self._check(self.lib.mnx_profile_read(self.h, C.byref(ms), C.byref(fl), C.byref(n)), "mnx_profile_read")
-        return ms.value, fl.value, n.value
+    PROFILE_KINDS = {"gemm": 0, "layernorm": 1, "window_attn": 2, "patch_embed": 3}
+
+    def profile_read(self, kind: str = "gemm", reset: bool = True):
+        """(ms, work, launches) accumulated by HIP events for one kernel class since the last reset; work = FLOP for
+        'gemm', algorithmic HBM bytes for the others."""
+        ms, wk, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.mnx_profile_read(self.h, self.PROFILE_KINDS[kind], C.byref(ms), C.byref(wk), C.byref(n)),
+                    "mnx_profile_read")
+        if reset:
+            self._check(self.lib.mnx_profile_read(self.h, -1, None, None, None), "mnx_profile_read")
+        return ms.value, wk.value, n.value
+
+    def profile_read_all(self):
+        out = {k: self.profile_read(k, reset=False) for k in self.PROFILE_KINDS}
+        self._check(self.lib.mnx_profile_read(self.h, -1, None, None, None), "mnx_profile_read")
+        return out
+
+    def probe_decode_attn(self, rows: int, t: int, iters: int = 20):
+        """Isolated timing of the two per-row decode attention kernels: (self_ms, cross_ms) per launch."""
+        a, b = C.c_double(), C.c_double()
+        self._check(self.lib.mnx_probe_decode_attn(self.h, rows, t, iters, C.byref(a), C.byref(b), _stream()),
+                    "mnx_probe_decode_attn")
+        return a.value, b.value
 
     def gemm16(self, epi: int, A: torch.Tensor, Wt: torch.Tensor, Cout: torch.Tensor, bias: Optional[torch.Tensor]):
         M, K = A.shape

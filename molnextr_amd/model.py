@@ -175,6 +175,7 @@ class molnextr:
         if len(input_images) == 0:
             return []                                      # reference model.py:101-102: empty loop, empty list
         cap = min(ROWS, self.engine.max_batch)
+        batch_size = min(batch_size, len(input_images))     # a batch larger than the job is the whole job: same numbering
         if batch_size < 1 or batch_size > cap:
             # results depend on the row inside the reference batch (positional-encoding quirk), so a silently
             # different batch size would silently change tokens

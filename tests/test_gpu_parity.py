@@ -366,6 +366,25 @@ def test_predict_results_do_not_depend_on_neighbouring_work(eng, dev):
     _same_predictions({k: v[64:] for k, v in whole.items()}, alone)
 
 
+def test_decode_is_bit_reproducible_under_concurrent_encoder_load(eng, dev):
+    """One batch decoded alone, then again while another stream keeps the chip busy with the encoder's store-heavy
+    GEMMs: tokens AND hidden states must be bit-identical. (Round 2 found a build whose per-row decode kernels were
+    reproducible alone but not next to the encoder: loads through re-used 64-bit VGPR address pairs returned wrong
+    data under memory back-pressure — DESIGN.md §6. The continuous-batching path always decodes next to the encoder.)"""
+    imgs = W.synthetic_images(32).to(dev)
+    f = eng.encode(imgs)
+    torch.cuda.synchronize()
+    ref = eng.decode_greedy(f, max_len=64, stop_on_eos=False)
+    side = torch.cuda.Stream()
+    for _ in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eng.encode(imgs)
+        r = eng.decode_greedy(f, max_len=64, stop_on_eos=False)
+        torch.cuda.synchronize()
+        assert torch.equal(r["tokens"], ref["tokens"]) and torch.equal(r["hidden"], ref["hidden"])
+
+
 def test_device_atom_scan_vs_reference_golden_and_fuzz(golden_dir, eng, dev):
     """The on-device restatement of sequence_to_smiles' 'indices': reference golden cases + a fuzz against the host
     tokenizer (itself pinned by the same golden cases)."""
