@@ -60,7 +60,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
                     const int ml = (PASSES == 1 ? wm * 64 : 0) + mt * 16 + fr;
                     f32x4 v = acc[nt][mt] + b4;
                     if (EPI == EPI_GELU_16) {
-                        v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
+                        v = gelu_fast4(v);
                     }
                     if (OUT16) {
                         v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
@@ -366,12 +366,20 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
     return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
 }
 
-hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
-                         const float* resid, int M, int N, int K, hipStream_t s) {
+hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                                 const float* resid, int M, int N, int K, hipStream_t s) {
     if ((K & 7) || (N & 7) || M <= 0) return hipErrorInvalidValue;
     if (dtype == MNX_DT_F32) return launch_f32(epi, A, W, C, bias, resid, M, N, K, s);
     return dtype == MNX_DT_F16 ? launch_t<f16_t>(epi, A, W, C, bias, resid, M, N, K, s)
                                : launch_t<bf16_t>(epi, A, W, C, bias, resid, M, N, K, s);
+}
+
+hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                         const float* resid, int M, int N, int K, hipStream_t s) {
+    // shape-only dispatch (never data- or environment-dependent): the persistent 256x256 kernel for the 16-bit-output
+    // layers whose tile count fills the chip, the 128x128 kernel for everything else
+    if (bias && gemm256_supports(dtype, epi, M, N, K)) return launch_gemm256(dtype, epi, A, W, C, bias, M, N, K, s);
+    return launch_gemm16_tile128(dtype, epi, A, W, C, bias, resid, M, N, K, s);
 }
 
 }  // namespace mnx

@@ -1,0 +1,298 @@
+// gemm256.hip — the persistent large-tile form of the encoder GEMM for its 16-bit-output layers (qkv: bias, fc1: bias +
+// GELU): C = epi(A.W^T + b), A [M,K], W [N,K] 16-bit, K contiguous; M and N multiples of 256, K a multiple of 64, >= 256.
+// launch_gemm16 (gemm.hip) routes here when gemm256_supports() says so; every other shape / epilogue stays on the
+// 128x128 kernel of gemm.hip.
+//
+// Why a second kernel (measurements: profiles/r02_gemm_shapes.md):
+//   * the 128x128 kernel moves 32 KiB through the L2 -> LDS fill path per 2.1 MFLOP K-step (64 FLOP/B); a CU issues
+//     4096 bf16 FLOP/clk but its fill path carries ~64 B/clk, so that tile saturates the fill path where the matrix
+//     pipe would saturate. A 256x256 tile needs half the bytes per FLOP;
+//   * with K = 256..1024 a tile is only 4..16 K-steps: prologue (first loads), epilogue (convert + store 128 KiB) and
+//     the GELU arithmetic were as long as the K loop and ran strictly after it. Here they overlap.
+//
+// Structure (gfx950, one 512-thread workgroup per CU, grid = min(tiles, 256), tile t -> workgroup t mod grid):
+//   * 256x256 output tile, 8 waves as 2 (M) x 4 (N), each wave 128x64 = 8x4 MFMA 16x16x32 tiles (128 accumulator
+//     registers), MFMA issued "swapped" so a lane owns 4 consecutive output columns of a row (as gemm.hip);
+//   * BK = 64. A K-tile lives in LDS as FOUR 16 KiB slots: Am0 / Am1 = the first / second 64 rows of each wave-row
+//     block, Bn0 / Bn1 = the first / second 32 weight rows of each wave-column block. Two K-tile buffers = 8 slots =
+//     128 KiB. Each slot is a [128][64] 16-bit image with the XOR swizzle of gemm.hip (conflict-free ds_read_b128),
+//     filled by global_load_lds_dwordx4 (2 per thread, scalar base + 32-bit lane offset);
+//   * a K-tile is TWO phases of 32 MFMAs per wave: phase A reads Am0 + Bn0 + Bn1 (16 ds_read_b128) and issues the fill
+//     of Am1 of the next K-tile; phase B reads Am1 (8) and issues the fills of Am0 + Bn0 + Bn1 of the K-tile after.
+//     Four slot-fills are in flight at every wait, retired with counted vmcnt (never 0 inside the stream);
+//   * the two wave rows (waves w and w+4 share a SIMD) run half a phase apart: one row's MFMAs cover the other row's
+//     LDS reads, waits and fill issue (one raw s_barrier before and one after each MFMA block);
+//   * the workgroup is persistent: the K-tile ring streams through all of its tiles without draining, so the first
+//     K-tiles of the next tile are loading while the finished tile is converted and stored;
+//   * epilogue: each wave transposes its 128x64 accumulator tile in 16-row slabs through a PRIVATE 2 KiB LDS patch (no
+//     workgroup barrier) and stores whole 128-byte lines, 16 bytes per lane. The second wave row runs its epilogue
+//     before its closing barrier, the first row after its own, so both run concurrently (measured: placed the same way
+//     for both rows, each row held the other at a barrier and the two epilogues ran one after the other);
+//   * GELU is gelu_fast4 (common.h): 17 fp32 operations per value. It remains exposed: the matrix pipe idles while the
+//     VALU converts (5-7 us of a ~20 us fc1 tile at K = 512).
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace mnx {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int SLOT = 128 * TK * 2;            // 16 KiB
+
+__device__ __forceinline__ int lds_off256(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// vmcnt bookkeeping (loads and stores retire in issue order): per tile a wave issues, besides the fills, 4 bias loads
+// (inline asm, at the tile's first K-tile) and 16 stores (epilogue). A wait that retires a fill issued BEFORE those
+// operations must allow them as younger operations; the exact counts are derived at each wait in the kernel. A count
+// that is too small only stalls, one that is too large would read a slot before it has landed.
+constexpr int P_STG = 2048;                        // per-wave staging patch: 16 rows x 64 columns of a 16-bit type
+constexpr int P_LDS = 8 * SLOT + 8 * P_STG;        // 144 KiB
+constexpr int P_STORES = 16, P_BIAS = 4;           // VMEM operations per wave per tile besides the fills
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W, T* __restrict__ C,
+                                                       const float* __restrict__ bias, int M, int N, int K, int tiles_n,
+                                                       int n_tiles) {
+    static_assert(EPI == EPI_BIAS_16 || EPI == EPI_GELU_16, "persistent form: 16-bit outputs only");
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 8 ring slots of 16 KiB + 8 staging patches
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / TK;
+    const int my_first = blockIdx.x, stride = gridDim.x;
+    const int my_tiles = (n_tiles - my_first + stride - 1) / stride;
+    const int total_kt = my_tiles * nk;                   // K-tiles this workgroup streams through the ring
+
+    // per-thread byte offsets of its two DMA pieces inside a tile (tile origin and K offset live in scalar registers)
+    const int r_in = lane >> 3, pc = lane & 7;
+    unsigned offA[2][2], offB[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = (wave * 2 + i) * 8 + r_in;
+        const int sw = (pc ^ ((s >> 1) & 7)) << 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            offA[h][i] = (unsigned)((((s >> 6) * 128 + h * 64 + (s & 63)) * K + sw) * 2);
+            offB[h][i] = (unsigned)((((s >> 5) * 64 + h * 32 + (s & 31)) * K + sw) * 2);
+        }
+    }
+    // the fill stream's position: K-tile `f` (slots 0..2 are issued two K-tiles ahead, slot 3 one K-tile ahead)
+    struct Pos { const char* a; const char* w; int kt, seq; };
+    auto tile_origin = [&](int seq, int& m0, int& n0) {
+        const int tile = xcd_remap(my_first + seq * stride, n_tiles);
+        m0 = (tile / tiles_n) * TM; n0 = (tile % tiles_n) * TN;
+    };
+    auto pos_at = [&](int seq) {
+        int m0, n0; tile_origin(seq, m0, n0);
+        Pos q; q.a = (const char*)(A + (size_t)m0 * K); q.w = (const char*)(W + (size_t)n0 * K); q.kt = 0; q.seq = seq;
+        return q;
+    };
+    auto advance = [&](Pos& q) {
+        if (++q.kt == nk) { if (q.seq + 1 < my_tiles) q = pos_at(q.seq + 1); else { q.kt = 0; ++q.seq; } }
+        else { q.a += TK * 2; q.w += TK * 2; }
+    };
+    auto fill = [&](const Pos& q, int par, auto slot_c) {
+        constexpr int sl = decltype(slot_c)::value;
+        char* dst = smem + (par * 4 + sl) * SLOT;
+        const char* base = (sl == 0 || sl == 3) ? q.a : q.w;
+        const unsigned o0 = sl == 0 ? offA[0][0] : sl == 1 ? offB[0][0] : sl == 2 ? offB[1][0] : offA[1][0];
+        const unsigned o1 = sl == 0 ? offA[0][1] : sl == 1 ? offB[0][1] : sl == 2 ? offB[1][1] : offA[1][1];
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + o0), (lds_void_t*)(dst + (wave * 2) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + o1), (lds_void_t*)(dst + (wave * 2 + 1) * 1024), 16, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
+
+    // bias of the tile being accumulated: 4 x 4 columns per lane, loaded by inline asm so that the loads are retired by
+    // the counted waits of the main loop (a compiler-tracked load would drain the whole ring at its first use)
+    f32x4 b4[4];
+    auto load_bias = [&](int n0) {
+        const float* bp = bias + n0 + wc * 64 + fg * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b4[nt]) : "v"(bp + nt * 16) : "memory");
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int m0, n0;
+    tile_origin(0, m0, n0);
+    load_bias(n0);
+    Pos p1 = pos_at(0);                           // K-tile gk + 1 (slot 3)
+    Pos p2 = p1;                                  // K-tile gk + 2 (slots 0..2)
+    fill(p1, 0, S0{}); fill(p1, 0, S1{}); fill(p1, 0, S2{}); fill(p1, 0, S3{});
+    advance(p1); p2 = p1;
+    fill(p2, 1, S0{}); fill(p2, 1, S1{}); fill(p2, 1, S2{});
+    advance(p2);
+    wait_vm<8>();                                 // bias + Am0, Bn0, Bn1 of K-tile 0 (Am1(0) and K-tile 1's three may fly)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row starts one segment late
+
+    char* stg = smem + 8 * SLOT + wave * P_STG;
+    v8 af[4][2], b0[2][2], b1[2][2];
+    int kt = 0, seq = 0;
+    auto epilogue = [&]() {
+        // ---- epilogue of tile `seq`: 16-row slabs of the wave tile through the wave's own staging patch ----
+        T* crow = C + (size_t)(m0 + wr * 128 + (lane >> 3)) * N + n0 + wc * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 v = acc[mt][nt] + b4[nt];
+                if (EPI == EPI_GELU_16) v = gelu_fast4(v);
+                const v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = o4;
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            // the wave's LDS operations execute in order: the reads below see the slab, the next slab's writes
+            // follow these reads
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (lane >> 3) + 8 * i;
+                const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                *(v8*)(crow + (size_t)(mt * 16 + 8 * i) * N) = o8;
+            }
+        }
+    };
+    for (int gk = 0; gk < total_kt; ++gk) {
+        const bool last_kt = (kt == nk - 1);
+        const char* buf = smem + (gk & 1) * 4 * SLOT;
+        const bool tail = gk + 2 >= total_kt;     // the ring is running dry: drain instead of counting
+        const bool first_kt = (kt == 0 && seq > 0), second_kt = (kt == 1 && seq > 0);
+        // ---- phase A: Am0 + Bn0 + Bn1 -> rows 0..63 of the wave tile ----
+        if (gk + 1 < total_kt) fill(p1, (gk + 1) & 1, S3{});
+        if (first_kt) load_bias(n0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                b0[j][ks] = *(const v8*)(buf + 1 * SLOT + lds_off256(wc * 32 + j * 16 + fr, ks * 4 + fg));
+                b1[j][ks] = *(const v8*)(buf + 2 * SLOT + lds_off256(wc * 32 + j * 16 + fr, ks * 4 + fg));
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const v8*)(buf + 0 * SLOT + lds_off256(wr * 64 + i * 16 + fr, ks * 4 + fg));
+        // Am1 of this K-tile, issued in phase A of the previous one. Younger: the 3 fills of phase B(gk-1), [the 16
+        // stores of the epilogue], this phase's fill [+ 4 bias loads]; after a tile's first K-tile the bias loads of
+        // that K-tile are younger than the fill issued just before them.
+        if (tail) wait_vm<0>();
+        else if (first_kt) wait_vm<8 + P_STORES + P_BIAS>();
+        else if (second_kt) wait_vm<8 + P_BIAS>();
+        else wait_vm<8>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = H16<T>::mfma(b0[j][ks], af[i][ks], acc[i][j]);
+                    acc[i][2 + j] = H16<T>::mfma(b1[j][ks], af[i][ks], acc[i][2 + j]);
+                }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B: Am1 -> rows 64..127 ----
+        if (gk + 2 < total_kt) { fill(p2, gk & 1, S0{}); fill(p2, gk & 1, S1{}); fill(p2, gk & 1, S2{}); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const v8*)(buf + 3 * SLOT + lds_off256(wr * 64 + i * 16 + fr, ks * 4 + fg));
+        // Am0, Bn0, Bn1 of the next K-tile, issued in phase B of the previous one. Younger: [16 stores], the fill of
+        // phase A(gk) [+ 4 bias loads], this phase's three fills.
+        if (tail) wait_vm<0>();
+        else if (first_kt) wait_vm<8 + P_STORES + P_BIAS>();
+        else wait_vm<8>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[4 + i][j] = H16<T>::mfma(b0[j][ks], af[i][ks], acc[4 + i][j]);
+                    acc[4 + i][2 + j] = H16<T>::mfma(b1[j][ks], af[i][ks], acc[4 + i][2 + j]);
+                }
+        __builtin_amdgcn_s_setprio(0);
+        // The tile's epilogue has no barrier of its own. The second wave row runs it BEFORE its closing barrier (which
+        // pairs with the first row's next opening barrier), the first row AFTER its own: both rows then convert and
+        // store at the same time instead of one after the other (each would otherwise hold the other at a barrier).
+        if (last_kt && wr == 1) epilogue();
+        __builtin_amdgcn_s_barrier();
+        if (last_kt && wr == 0) epilogue();
+        p1 = p2;
+        advance(p2);
+        if (last_kt) {
+            kt = 0; ++seq;
+            if (seq < my_tiles) tile_origin(seq, m0, n0);
+        } else {
+            ++kt;
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();    // the first wave row waits for the second one's last segment
+}
+
+}  // namespace
+
+bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
+    if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16) return false;
+    if (epi != EPI_BIAS_16 && epi != EPI_GELU_16) return false;
+    if (M % TM || N % TN || K % TK || K < 4 * TK) return false;
+    // one workgroup per CU walks tiles in rounds of 256: below one round, or when the last round is mostly empty, the
+    // 128x128 kernel fills the chip better
+    const int tiles = (M / TM) * (N / TN), rounds = (tiles + 255) / 256;
+    return tiles >= 256 && tiles * 10 >= rounds * 256 * 7;
+}
+
+hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
+                          int K, hipStream_t s) {
+    if (!bias || M % TM || N % TN || K % TK || K < 4 * TK) return hipErrorInvalidValue;
+    const int tm = M / TM, tn = N / TN;
+    const int grid = tm * tn < 256 ? tm * tn : 256;
+#define MNX_G256_CASE(TT, E)                                                                                              \
+    case E: {                                                                                                             \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)gemm256_kernel<TT, E>,                            \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);            \
+        if (attr != hipSuccess) return attr;                                                                              \
+        hipLaunchKernelGGL((gemm256_kernel<TT, E>), dim3(grid), dim3(512), P_LDS, s, (const TT*)A, (const TT*)W, (TT*)C,  \
+                           bias, M, N, K, tn, tm * tn);                                                                   \
+        break;                                                                                                            \
+    }
+    if (dtype == MNX_DT_F16) {
+        switch (epi) { MNX_G256_CASE(f16_t, EPI_BIAS_16) MNX_G256_CASE(f16_t, EPI_GELU_16) default: return hipErrorInvalidValue; }
+    } else {
+        switch (epi) { MNX_G256_CASE(bf16_t, EPI_BIAS_16) MNX_G256_CASE(bf16_t, EPI_GELU_16) default: return hipErrorInvalidValue; }
+    }
+#undef MNX_G256_CASE
+    return hipGetLastError();
+}
+
+}  // namespace mnx

@@ -13,6 +13,14 @@ enum { EPI_BIAS_16 = 0, EPI_GELU_16 = 1, EPI_RESID_F32 = 2, EPI_BIAS_F32 = 3 };
 // C[M,N] = epi(A[M,K] . W[N,K]^T + bias). A, W 16-bit (dtype). resid/C fp32 for EPI_RESID_F32 (may alias).
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                          const float* resid, int M, int N, int K, hipStream_t s);
+// the 128x128-tile kernel of gemm.hip without the dispatch to gemm256.hip (tools/gemm_lab compares the two)
+hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                                 const float* resid, int M, int N, int K, hipStream_t s);
+
+// ---- gemm256.hip: persistent 256x256-tile form for the 16-bit-output epilogues (bias, bias + GELU); bias required ----
+bool gemm256_supports(int dtype, int epi, int M, int N, int K);   // shape / epilogue fit AND the tile count fills 256 CUs
+hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
+                          int K, hipStream_t s);
 
 // ---- encoder.hip ----------------------------------------------------------------------------
 // images [B,3,S,S] fp32 NCHW -> x [B,(S/4)^2,C] fp32 (conv 4x4/4 + bias + LayerNorm, eps 1e-5)

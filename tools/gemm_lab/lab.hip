@@ -1,0 +1,149 @@
+// tools/gemm_lab/lab.hip — standalone A/B bench of the encoder GEMM kernels on the Swin-B shapes (no Python, no engine).
+//
+//   make -C tools/gemm_lab && tools/gemm_lab/lab [images_per_group=64] [iters=20] [only-names,comma-separated]
+//
+// For every (stage, layer) GEMM shape of an encoder group it checks sampled output rows of both kernels against a naive
+// fp32 reference (same 16-bit inputs) and prints microseconds and TFLOP/s of
+//   base = the 128x128 kernel of gemm.hip          (mnx::launch_gemm16_tile128)
+//   disp = what the product dispatches              (mnx::launch_gemm16: gemm256.hip where gemm256_supports())
+// The table under profiles/ (r02_gemm_shapes.md) is this program's output.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+#define CK(x)                                                                                     \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));   \
+            exit(1);                                                                              \
+        }                                                                                         \
+    } while (0)
+
+__global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (bf16_t)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
+    }
+}
+__global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = ((int)(h & 0xffff) - 32768) * (scale / 32768.f);
+    }
+}
+// reference for sampled rows: out[s][n] = epi(sum_k A[row_s][k] * W[n][k] + bias[n]) (+ resid)
+__global__ void ref_rows(const bf16_t* A, const bf16_t* W, const float* bias, const float* resid, const int* rows,
+                         int S, int N, int K, int epi, float* out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (n >= N) return;
+    const int m = rows[s];
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += (float)A[(size_t)m * K + k] * (float)W[(size_t)n * K + k];
+    acc += bias[n];
+    if (epi == 1) acc = 0.5f * acc * (1.0f + erff(acc * 0.70710678f));
+    if (epi == 2) acc += resid[(size_t)m * N + n];
+    out[(size_t)s * N + n] = acc;
+}
+
+struct Shape { const char* name; int epi, M, N, K; };
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64;
+    const int iters = argc > 2 ? atoi(argv[2]) : 20;
+    const char* only = argc > 3 ? argv[3] : nullptr;
+    std::vector<Shape> shapes;
+    const int L[4] = {9216, 2304, 576, 144}, C[4] = {128, 256, 512, 1024};
+    static char names[64][32];
+    int ni = 0;
+    for (int si : {0, 1, 2, 3}) {
+        const int M = B * L[si], c = C[si];
+        snprintf(names[ni], 32, "qkv s%d", si); shapes.push_back({names[ni++], 0, M, 3 * c, c});
+        snprintf(names[ni], 32, "proj s%d", si); shapes.push_back({names[ni++], 2, M, c, c});
+        snprintf(names[ni], 32, "fc1 s%d", si); shapes.push_back({names[ni++], 1, M, 4 * c, c});
+        snprintf(names[ni], 32, "fc2 s%d", si); shapes.push_back({names[ni++], 2, M, c, 4 * c});
+        if (si < 3) { snprintf(names[ni], 32, "merge s%d", si); shapes.push_back({names[ni++], 3, M / 4, 2 * c, 4 * c}); }
+    }
+    shapes.push_back({"sq8192", 0, 8192, 8192, 8192});
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("images per group %d, %d launches per timing\n", B, iters);
+    printf("%-9s epi %8s %6s %6s | %10s %8s | %10s %8s %-6s| max |err| vs fp32 reference (base, disp)\n", "shape", "M", "N",
+           "K", "base us", "TF", "disp us", "TF", "kernel");
+    for (const Shape& sh : shapes) {
+        if (only && !strstr(only, sh.name)) continue;
+        const bool out16 = sh.epi < 2;
+        const size_t nA = (size_t)sh.M * sh.K, nW = (size_t)sh.N * sh.K, nC = (size_t)sh.M * sh.N;
+        bf16_t *A, *W;
+        float *bias, *resid0;
+        void* Cc;
+        CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&W, nW * 2)); CK(hipMalloc(&bias, sh.N * 4));
+        CK(hipMalloc(&Cc, nC * (out16 ? 2 : 4)));
+        CK(hipMalloc(&resid0, sh.epi == 2 ? nC * 4 : 16));
+        fill_bf16<<<2048, 256, 0, st>>>(A, nA, 1u, 1.0f);
+        fill_bf16<<<2048, 256, 0, st>>>(W, nW, 2u, 1.0f / sqrtf((float)sh.K));
+        fill_f32<<<64, 256, 0, st>>>(bias, sh.N, 3u, 0.5f);
+        if (sh.epi == 2) fill_f32<<<2048, 256, 0, st>>>(resid0, nC, 4u, 1.0f);
+        const int S = 24;
+        std::vector<int> rows(S);
+        for (int i = 0; i < S; ++i) rows[i] = (int)(((long long)i * 2654435761ll + 17) % sh.M);
+        rows[0] = 0; rows[1] = sh.M - 1; rows[2] = sh.M / 2 + 255 < sh.M ? sh.M / 2 + 255 : sh.M - 1;
+        int* drows; float* ref;
+        CK(hipMalloc(&drows, S * 4)); CK(hipMalloc(&ref, (size_t)S * sh.N * 4));
+        CK(hipMemcpyAsync(drows, rows.data(), S * 4, hipMemcpyHostToDevice, st));
+        ref_rows<<<dim3((sh.N + 127) / 128, S), 128, 0, st>>>(A, W, bias, resid0, drows, S, sh.N, sh.K, sh.epi, ref);
+        std::vector<float> href((size_t)S * sh.N);
+        CK(hipMemcpyAsync(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        const bool uses256 = mnx::gemm256_supports(mnx::MNX_DT_BF16, sh.epi, sh.M, sh.N, sh.K);
+        auto launch = [&](int v) {
+            const float* resid = sh.epi == 2 ? (const float*)Cc : nullptr;      // in-place residual, as the encoder runs it
+            return v ? mnx::launch_gemm16(mnx::MNX_DT_BF16, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st)
+                     : mnx::launch_gemm16_tile128(mnx::MNX_DT_BF16, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st);
+        };
+        double us[2] = {0, 0}, err[2] = {0, 0};
+        for (int v = 0; v < 2; ++v) {
+            if (sh.epi == 2) CK(hipMemcpyAsync(Cc, resid0, nC * 4, hipMemcpyDeviceToDevice, st));
+            CK(launch(v));
+            std::vector<char> hrow((size_t)sh.N * 4);
+            for (int i = 0; i < S; ++i) {
+                CK(hipMemcpyAsync(hrow.data(), (char*)Cc + (size_t)rows[i] * sh.N * (out16 ? 2 : 4), (size_t)sh.N * (out16 ? 2 : 4),
+                                  hipMemcpyDeviceToHost, st));
+                CK(hipStreamSynchronize(st));
+                for (int n = 0; n < sh.N; ++n) {
+                    float got;
+                    if (out16) { unsigned u = ((unsigned)((unsigned short*)hrow.data())[n]) << 16; memcpy(&got, &u, 4); }
+                    else got = ((float*)hrow.data())[n];
+                    const double d = fabs((double)got - href[(size_t)i * sh.N + n]);
+                    if (d > err[v]) err[v] = d;
+                }
+            }
+            for (int i = 0; i < 3; ++i) CK(launch(v));     // warm (epi 2 keeps accumulating in place: values irrelevant here)
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) CK(launch(v));
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            us[v] = ms * 1000.0 / iters;
+        }
+        const double fl = 2.0 * sh.M * sh.N * sh.K;
+        const double tol = out16 ? 2e-2 : 1e-3;
+        printf("%-9s %3d %8d %6d %6d | %10.1f %8.1f | %10.1f %8.1f %-6s| %.2e %.2e%s\n", sh.name, sh.epi, sh.M, sh.N, sh.K, us[0],
+               fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, uses256 ? "g256" : "base", err[0], err[1],
+               (err[0] > tol || err[1] > tol) ? "  FAIL" : "");
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(Cc)); CK(hipFree(resid0)); CK(hipFree(drows)); CK(hipFree(ref));
+    }
+    return 0;
+}

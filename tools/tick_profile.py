@@ -20,13 +20,14 @@ def main(path, out=None):
         if "dec_begin_kernel" in name or "beam_begin_kernel" in name:
             if cur:
                 ticks.append(cur)
-            cur = {"start": st, "sid": sid, "kern": 0.0, "n": 0, "cap": None, "last_end": en}
+            cur = {"start": st, "sid": sid, "kern": 0.0, "n": 0, "cap": None, "last_end": en, "seq": []}
         if cur is None or sid != cur["sid"]:
             continue
         if not ("dec_" in name or "beam_" in name):
             continue
         cur["kern"] += en - st
         cur["n"] += 1
+        cur["seq"].append((name.split("(")[0][-40:], (en - st) / 1e3, gx // max(wx, 1) * (gy // max(wy, 1))))
         cur["last_end"] = max(cur["last_end"], en)
         if cur["cap"] is None and "dec_linear" in name:
             cur["cap"] = (gy // max(wy, 1)) * 32
@@ -43,6 +44,36 @@ def main(path, out=None):
         w = sorted(x[0] for x in v)
         lines.append(f"{cap:8d} {len(v):6d} {statistics.median(w):11.1f} {w[len(w) // 10]:11.1f} "
                      f"{statistics.median(x[1] for x in v):11.1f} {statistics.median(x[3] for x in v):11.1f} {v[0][2]:8d}")
+    # per-launch view of a tick: median duration of the i-th kernel of the tick, for the smallest and largest capacity
+    for cap in (min(k for k in by if k), max(k for k in by if k)):
+        sel = [t for t in ticks if t["cap"] == cap and len(t["seq"]) == 50]
+        if not sel:
+            continue
+        lines.append("")
+        lines.append(f"tick at rows_cap {cap}: i-th launch, median us over {len(sel)} ticks, workgroups")
+        for i in range(50):
+            d = sorted(t["seq"][i][1] for t in sel)
+            lines.append(f"  {i:2d} {sel[0]['seq'][i][0]:40s} {d[len(d) // 2]:7.2f} {sel[0]['seq'][i][2]:6d}")
+    # timeline: 10 ms bins — decode ticks (count, median row capacity, busy) and encoder busy time per bin
+    t0 = rows[0][1]
+    nb = int((rows[-1][2] - t0) / 1e7) + 1
+    enc = [0.0] * nb
+    dec = [0.0] * nb
+    for name, st, en, gx, gy, wx, wy, sid in rows:
+        b = int((st - t0) / 1e7)
+        if "dec_" in name or "beam_" in name or "head_" in name:
+            dec[b] += (en - st) / 1e3
+        else:
+            enc[b] += (en - st) / 1e3
+    tk = defaultdict(list)
+    for t in ticks:
+        tk[int((t["start"] - t0) / 1e7)].append(t["cap"] or 0)
+    lines.append("")
+    lines.append(f"{'t_ms':>6s} {'ticks':>6s} {'cap_med':>8s} {'cap_max':>8s} {'dec_busy_us':>12s} {'other_busy_us':>14s}")
+    for b in range(nb):
+        caps = tk.get(b, [])
+        lines.append(f"{b * 10:6d} {len(caps):6d} {int(statistics.median(caps)) if caps else 0:8d} {max(caps) if caps else 0:8d} "
+                     f"{dec[b]:12.0f} {enc[b]:14.0f}")
     txt = "\n".join(lines)
     print(txt)
     if out:
