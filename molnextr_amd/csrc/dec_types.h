@@ -30,6 +30,13 @@ struct DecState {
     int max_len[MAX_SLOTS];
     int stop_on_eos[MAX_SLOTS];
     int active[MAX_SLOTS];         // compact list of the alive slots for the current tick (rows 0..n_active-1)
+    // Row view of the tick, written by the begin kernel for EVERY row up to the scanned capacity: {slot, t, prev_tok,
+    // PE rank} and the memory block. The tick's kernels read these with the row index alone, in parallel with
+    // n_active, instead of chasing n_active -> active[row] -> t[slot] (each hop a memory round trip on the critical
+    // path of a 5 us kernel). Rows >= n_active hold a harmless dummy (slot 0, position 0, block 0): kernels may read
+    // and compute on them and only have to keep them from WRITING per-slot state.
+    int4 rowv[MAX_SLOTS];
+    int row_mem[MAX_SLOTS];
 };
 
 struct DecLayerW {

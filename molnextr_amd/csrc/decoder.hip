@@ -116,42 +116,48 @@ struct LinArgs {
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     // fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain) on a 32-row x 32-column tile; the 4 waves split K.
+    // Latency is what this kernel costs (5-10 us at any row count, a tick is 50 of them): every load that does not
+    // depend on the tick's state (weights, the input slab, the row view) is issued before anything is waited for, there
+    // is no early exit to hide loads behind (an idle tile computes on zeros and stores nothing), and for K > 256 the
+    // next K chunk is in flight while the current one is multiplied.
     __shared__ __attribute__((aligned(16))) float xs[32 * XS];   // input slab; reused as the cross-wave reduction buffer
     __shared__ __attribute__((aligned(16))) float ws[TN * XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * TN;
     const int row0 = blockIdx.y * ROW_TILE;          // rows are positions in the tick's compact active list
-    const int n_act = a.st->n_active;
-    if (row0 >= n_act) return;                       // whole tile idle
     // LayerNorm / embedding / staging thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
     const int lrow = tid >> 3, part = tid & 7;
+    f32x4 xv[8], wv[8];
+    const float* wsrc = a.W + (size_t)(n0 + lrow) * a.K + part * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(wsrc + 32 * j);
+    const int4 rv = a.st->rowv[row0 + lrow];         // {slot, t, prev_tok, rank}; dummy beyond n_active
+    const float* src = a.in + (size_t)(row0 + lrow) * a.K + part * 4;
+    if (PRO != 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = *(const f32x4*)(src + 32 * j);
+    }
+    const int n_act = a.st->n_active;
+    const f32x4 bias4 = *(const f32x4*)(a.bias + n0 + part * 4);
+    f32x4 res4 = {0.f, 0.f, 0.f, 0.f};               // EPI 1: the residual elements this thread updates in place
+    if (EPI == 1) res4 = *(const f32x4*)(a.out + (size_t)(row0 + lrow) * a.N + n0 + part * 4);
+    if (PRO == 2) {
+        // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
+        const float* e = a.emb + (size_t)rv.z * 256 + part * 4;
+        const float* p = a.pe + (size_t)rv.w * 256 + part * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = *(const f32x4*)(e + 32 * j) * 16.0f + *(const f32x4*)(p + 32 * j);
+    }
     const bool live = row0 + lrow < n_act;
-    const int lslot = live ? a.st->active[row0 + lrow] : 0;
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     for (int k0 = 0; k0 < a.K; k0 += 256) {
-        // ---- stage the input slab [32, 256] and the weight tile [32, 256]: all loads first, then LDS stores ----
-        f32x4 xv[8], wv[8];
-        if (PRO == 2) {
-            // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
-            const float* e = a.emb + (size_t)a.st->prev_tok[lslot] * 256 + part * 4;
-            const float* p = a.pe + (size_t)a.st->rank[lslot] * 256 + part * 4;
+        // ---- xv / wv hold the input slab [32, 256] and the weight tile [32, 256] of this K chunk ----
+        if (!live) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xv[j] = live ? *(const f32x4*)(e + 32 * j) * 16.0f + *(const f32x4*)(p + 32 * j)
-                             : (f32x4){0.f, 0.f, 0.f, 0.f};
-        } else {
-            const float* src = a.in + (size_t)(row0 + lrow) * a.K + k0 + part * 4;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xv[j] = live ? *(const f32x4*)(src + 32 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        {
-            const float* wsrc = a.W + (size_t)(n0 + lrow) * a.K + k0 + part * 4;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(wsrc + 32 * j);
+            for (int j = 0; j < 8; ++j) xv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (PRO == 2 && blockIdx.x == 0 && live) {
 #pragma unroll
@@ -182,6 +188,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
             *(f32x4*)(xs + lrow * XS + part * 4 + 32 * j) = xv[j];
             *(f32x4*)(ws + lrow * XS + part * 4 + 32 * j) = wv[j];
         }
+        if (k0 + 256 < a.K) {                        // next K chunk: in flight during this chunk's MFMAs
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wv[j] = *(const f32x4*)(wsrc + k0 + 256 + 32 * j);
+                xv[j] = *(const f32x4*)(src + k0 + 256 + 32 * j);
+            }
+        }
         __syncthreads();
         // wave w owns k in [64w, 64w+64): per 16-k chunk one ds_read_b128 per operand tile feeds 4 MFMA k-steps
         // (k-slot (step j, lane group g) <-> k = kb + 4g + j on BOTH operands, so the contraction is unchanged)
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
             for (int r = 0; r < 4; ++r)
                 red[(wave * 32 + mt * 16 + fg * 4 + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
     __syncthreads();
-    const int slot = lslot;                           // persistent state (caches) is per slot,
+    const int slot = rv.x;                            // persistent state (caches) is per slot,
     const int row = row0 + lrow;                      // activations of this tick are per active-list row
     if (!live) return;
     const int nc = part * 4;                          // 4 consecutive output columns per thread
@@ -220,18 +233,17 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
         v[u] = (red[(0 * 32 + lrow) * 33 + nc + u] + red[(1 * 32 + lrow) * 33 + nc + u]) +
                (red[(2 * 32 + lrow) * 33 + nc + u] + red[(3 * 32 + lrow) * 33 + nc + u]);
     const int n = n0 + nc;
-    v += *(const f32x4*)(a.bias + n);
+    v += bias4;
     if (EPI == 0) {
         const int part_ = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
         if (part_ == 0) {
             *(f32x4*)(a.out + (size_t)row * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
         } else {
             float* cache = part_ == 1 ? a.kcache : a.vcache;
-            *(f32x4*)(cache + (((size_t)slot * a.heads + hd) * a.T + a.st->t[slot]) * 32 + d) = v;
+            *(f32x4*)(cache + (((size_t)slot * a.heads + hd) * a.T + rv.y) * 32 + d) = v;
         }
     } else if (EPI == 1) {
-        float* o = a.out + (size_t)row * a.N + n;
-        *(f32x4*)o = *(const f32x4*)o + v;
+        *(f32x4*)(a.out + (size_t)row * a.N + n) = res4 + v;
     } else if (EPI == 2) {
         *(f32x4*)(a.out + (size_t)row * a.N + n) = v * 0.17677669529663687f;
     } else {
@@ -269,10 +281,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float po[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
-    if (row >= a.st->n_active) return;
-    const int slot = a.st->active[row];
-    const int nkeys = a.cross ? a.fixed_keys : a.st->t[slot] + 1;
-    const long long rowb = a.cross ? (long long)a.st->mem_blk[slot] : (long long)slot;
+    // no n_active here: an idle row carries the dummy row view (slot 0 at position 0, memory block 0), computes a
+    // throw-away context row and touches no per-slot state — one dependent round trip less before the key loads
+    const int4 rv = a.st->rowv[row];
+    const int slot = rv.x;
+    const int nkeys = a.cross ? a.fixed_keys : rv.y + 1;
+    const long long rowb = a.cross ? (long long)a.st->row_mem[row] : (long long)slot;
     const float* Kb = a.K + rowb * a.row_stride + hd * a.head_stride;
     const float* Vb = a.V + rowb * a.row_stride + hd * a.head_stride;
     f32x4 q[8];
@@ -376,11 +390,13 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __shared__ int redi[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
-    if (row >= a.st->n_active) return;
-    const int slot = a.st->active[row];
-    const int t = a.st->t[slot];
+    const int4 rv = a.st->rowv[row];
+    const int n_act = a.st->n_active;
+    f32x4 xrow = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
+    if (row >= n_act) return;
+    const int slot = rv.x, t = rv.y;
     if (wave == 0) {
-        f32x4 v = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
+        f32x4 v = xrow;
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
         v -= mean;
         const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
@@ -414,7 +430,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __syncthreads();
     const float lse = m + logf(red[4] + red[5] + red[6] + red[7]);
     float lp = logit - lse;
-    const int prev = a.st->prev_tok[slot];
+    const int prev = rv.z;
     if (prev >= a.x0 && prev < a.y0) { if (tid < a.y0) lp = -10000.0f; }     // after an x-bin: only y-bins
     else if (prev >= a.y0)           { if (tid >= a.x0) lp = -10000.0f; }    // after a y-bin: no coordinate bins
     if (t == 0 && tid == a.eos) lp = -1e20f;                                  // min_length = 1
@@ -484,6 +500,20 @@ __global__ __launch_bounds__(BEGIN_THREADS) void dec_begin_kernel(DecState* st, 
         }
     if (tid < MAX_CHUNKS) st->chunk_alive[tid] = __popc(s_mask[tid]);
     if (tid == 0) { st->n_active = s_base; st->tick = st->tick + 1; }
+    // row view (dec_types.h): active[] and rank[] above were written by other threads of this workgroup
+    __syncthreads();
+    const int n = s_base;
+    for (int r = tid; r < slots; r += BEGIN_THREADS) {
+        int4 v = {0, 0, 0, 0};
+        int mb = 0;
+        if (r < n) {
+            const int s = st->active[r];
+            v = (int4){s, st->t[s], st->prev_tok[s], st->rank[s]};
+            mb = st->mem_blk[s];
+        }
+        st->rowv[r] = v;
+        st->row_mem[r] = mb;
+    }
 }
 
 __global__ __launch_bounds__(BEGIN_THREADS) void dec_reset_kernel(DecState* st) {
@@ -894,6 +924,18 @@ __global__ void beam_begin_kernel(DecState* st, int B, int K) {
         }
     }
     if (tid == 0) { st->n_active = total * K; st->chunk_alive[0] = total * K; st->tick = st->tick + 1; }
+    __syncthreads();
+    for (int r = tid; r < ((B * K + ROW_TILE - 1) & ~(ROW_TILE - 1)); r += blockDim.x) {     // row view (dec_types.h)
+        int4 v = {0, 0, 0, 0};
+        int mb = 0;
+        if (r < total * K) {
+            const int s = st->active[r];
+            v = (int4){s, st->t[s], st->prev_tok[s], st->rank[s]};
+            mb = st->mem_blk[s];
+        }
+        st->rowv[r] = v;
+        st->row_mem[r] = mb;
+    }
 }
 
 __global__ __launch_bounds__(256) void beam_pick_kernel(DecState* st, BeamBuffers bm, const float* hidden, int* etok,
