@@ -62,7 +62,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // GELU for 16-bit outputs (encoder MLP) on the packed fp32 pipe. x * Phi(x) with
 // Phi(x) = 0.5 + xc * Q(u), xc = clamp(x, -5, 5), u = 2 xc^2 / 25 - 1, Q = degree-12 Chebyshev fit of (Phi(x) - 0.5) / x
 // converted to monomials in u (sum |coef| = 0.4, so fp32 Horner is well conditioned). |error| <= 2.3e-6 absolute over the
-// reals (checked against scipy erf, tests/test_host_logic.py), far below the bf16/fp16 rounding of the stored result.
+// reals (checked against scipy erf in float32, tests/test_device_math.py), far below the bf16/fp16 rounding of the stored result.
 // 9 full-rate VALU operations per value instead of the 12 + two quarter-rate transcendentals (rcp, exp2) of an
 // exp-based erf: the GELU epilogue of fc1 was VALU-bound. The fp32 parity mode uses erff.
 // Four values per call: the two packed chains are independent, so back-to-back dependent packed operations (which cost a

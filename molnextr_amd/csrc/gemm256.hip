@@ -1,5 +1,5 @@
 // gemm256.hip — the persistent large-tile form of the encoder GEMM for its 16-bit-output layers (qkv: bias, fc1: bias +
-// GELU): C = epi(A.W^T + b), A [M,K], W [N,K] 16-bit, K contiguous; M and N multiples of 256, K a multiple of 64, >= 256.
+// GELU): C = epi(A.W^T + b), A [M,K], W [N,K] 16-bit, K contiguous; M and N multiples of 256, K a multiple of 64, >= 128.
 // launch_gemm16 (gemm.hip) routes here when gemm256_supports() says so; every other shape / epilogue stays on the
 // 128x128 kernel of gemm.hip.
 //
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
     if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16) return false;
     if (epi != EPI_BIAS_16 && epi != EPI_GELU_16) return false;
-    if (M % TM || N % TN || K % TK || K < 4 * TK) return false;
+    if (M % TM || N % TN || K % TK || K < 2 * TK) return false;
     // one workgroup per CU walks tiles in rounds of 256: below one round, or when the last round is mostly empty, the
     // 128x128 kernel fills the chip better
     const int tiles = (M / TM) * (N / TN), rounds = (tiles + 255) / 256;
@@ -274,7 +274,7 @@ bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
 
 hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
                           int K, hipStream_t s) {
-    if (!bias || M % TM || N % TN || K % TK || K < 4 * TK) return hipErrorInvalidValue;
+    if (!bias || M % TM || N % TN || K % TK || K < 2 * TK) return hipErrorInvalidValue;
     const int tm = M / TM, tn = N / TN;
     const int grid = tm * tn < 256 ? tm * tn : 256;
 #define MNX_G256_CASE(TT, E)                                                                                              \

@@ -70,6 +70,32 @@ def test_gemm_all_epilogues(eng, dev, M, N, K):
     assert (r2 - (ref + res)).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(65536, 256, 128), (16384, 1024, 256), (18432, 2048, 512), (9216, 3072, 1024)])
+def test_gemm_persistent_256_tile_kernel(dev, dtype, M, N, K):
+    """Shapes that launch_gemm16 routes to gemm256.hip (M, N multiples of 256, >= 256 tiles, 16-bit-output epilogues):
+    one round (256 tiles), the two-K-tile case (K = 128), several rounds with a ragged last one; bias and bias + GELU,
+    both 16-bit types; every output element is compared (tile seams, first / last tile of every workgroup)."""
+    e = _tiny_engine(dtype)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev).to(td)
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(td)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = A.float() @ Wt.float().t() + bias
+    tol = 4e-2 if dtype == "bf16" else 6e-3
+    o16 = torch.zeros(M, N, device=dev, dtype=td)
+    e.gemm16(0, A, Wt, o16, bias)
+    assert (o16.float() - ref).abs().max().item() < tol
+    o16.zero_()
+    e.gemm16(1, A, Wt, o16, bias)
+    assert (o16.float() - torch.nn.functional.gelu(ref)).abs().max().item() < tol
+    again = torch.zeros_like(o16)
+    e.gemm16(1, A, Wt, again, bias)
+    assert torch.equal(again, o16)                       # same launch twice: bit-identical
+    e.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [("bf16", 4e-2), ("fp16", 6e-3)])
 def test_swin_tiny_every_block_vs_reference_golden(golden_dir, dev, dtype, tol):
     gold = np.load(os.path.join(golden_dir, "swin_tiny.npz"))

@@ -17,10 +17,10 @@ def per_kernel(db, counter):
 
 f = per_kernel(sys.argv[1], "FETCH_SIZE")
 w = per_kernel(sys.argv[2], "WRITE_SIZE")
-tot_f = sum(v[0] for k, v in f.items() if "gemm_tn" in k)
-n_f = sum(v[1] for k, v in f.items() if "gemm_tn" in k)
-tot_w = sum(v[0] for k, v in w.items() if "gemm_tn" in k)
-n_w = sum(v[1] for k, v in w.items() if "gemm_tn" in k)
+tot_f = sum(v[0] for k, v in f.items() if "gemm_tn" in k or "gemm256" in k)
+n_f = sum(v[1] for k, v in f.items() if "gemm_tn" in k or "gemm256" in k)
+tot_w = sum(v[0] for k, v in w.items() if "gemm_tn" in k or "gemm256" in k)
+n_w = sum(v[1] for k, v in w.items() if "gemm_tn" in k or "gemm256" in k)
 out = {"kernel": f"gemm_tn*_kernel (all encoder GEMM launches of Swin-B @ B={sys.argv[4] if len(sys.argv) > 4 else 32})", "launches_per_pass": n_f,
        "read_bytes_per_launch": 2 * tot_f * 1024 / n_f, "write_bytes_per_launch": tot_w * 1024 / n_w,
        "hbm_bytes_per_launch": (2 * tot_f / n_f + tot_w / n_w) * 1024,

@@ -6,6 +6,7 @@ import sys
 
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*$", "", n)
     n = n.replace("void ", "").replace("mnx::", "")
     return n[:78]
