@@ -9,8 +9,10 @@
  * Each entry point below names the reference code it replaces. All functions are `extern "C"`, take plain
  * pointers and sizes (no torch / C++ types), return 0 on success or a negative mnx_status, never throw, and
  * enqueue their GPU work on the caller's HIP stream. Device pointers are raw HBM addresses (e.g. a PyTorch-ROCm
- * tensor's data_ptr()). A handle is bound to one device and is not re-entrant: one in-flight call per handle;
- * different handles (GPUs) may be driven from different threads or processes. The only process-wide state is the
+ * tensor's data_ptr()). A handle is bound to one device and is not re-entrant: one in-flight call per handle —
+ * except that ONE mnx_preprocess call (its only state is a private 16-byte scratch) may run on another thread and
+ * stream beside any other entry point, so that the next images can be uploaded and transformed while mnx_predict
+ * works; different handles (GPUs) may be driven from different threads or processes. The only process-wide state is the
  * message of the last failed mnx_create (read it with mnx_last_error(NULL) from the thread that called mnx_create).
  */
 #ifndef MOLNEXTR_HIP_H

@@ -476,6 +476,7 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->feat_ring[1] = (float*)P.dalloc(ring_rows * S * CF * 4);
     h->slot_lists = (int*)P.dalloc((size_t)MAX_CHUNKS * ROW_TILE * 4);
     h->tc_dev = (TokenClasses*)P.dalloc(sizeof(TokenClasses));
+    h->prep_bbox = (int*)P.dalloc(4 * sizeof(int));   // at create: mnx_preprocess may run beside another entry point
     {
         // Encoder and decoder run concurrently on separate streams; the encoder stream gets the high priority (its
         // large GEMM grids otherwise queue behind the decode ticks' many small kernels: measured +1.6 %). Partitioning
@@ -765,10 +766,6 @@ int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t wi
     if (!rgb || !out || height < 1 || width < 1 || pad < 0) { h->err = "mnx_preprocess: null/empty argument"; return MNX_ERR_INVALID_ARG; }
     if (height > 16384 || width > 16384 || pad > 4096) { h->err = "mnx_preprocess: image larger than 16384x16384"; return MNX_ERR_CAPACITY; }
     HIPCHK(h, hipSetDevice(h->device));
-    if (!h->prep_bbox) {
-        HIPCHK(h, hipMalloc((void**)&h->prep_bbox, 4 * sizeof(int)));
-        h->allocs.push_back(h->prep_bbox);
-    }
     HIPCHK(h, launch_preprocess(rgb, height, width, pad, pad_to_square ? 1 : 0, h->cfg.img_size, h->prep_bbox, crop_out, out,
                                 (hipStream_t)stream));
     return MNX_OK;

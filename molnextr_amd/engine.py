@@ -236,10 +236,20 @@ class Engine:
         crops = torch.zeros(len(images), 4, dtype=torch.int32, device=dev) if return_crops else None
         keep = []
         for i, im in enumerate(images):
-            t = torch.as_tensor(np.ascontiguousarray(im))
-            if t.dim() == 2:
-                t = t[..., None].expand(-1, -1, 3)
-            t = t[..., :3].to(dtype=torch.uint8).contiguous().to(dev, non_blocking=True)
+            if torch.is_tensor(im) and im.is_cuda:
+                t = im if im.dim() == 3 else im[..., None].expand(-1, -1, 3)
+                t = t[..., :3].to(dtype=torch.uint8).contiguous()
+            else:
+                a = np.asarray(im)
+                if a.ndim == 2:
+                    a = np.repeat(a[..., None], 3, axis=2)
+                a = np.ascontiguousarray(a[..., :3], dtype=np.uint8)
+                # page -> pinned staging -> device: the H2D copy is then truly asynchronous on this stream (a pageable
+                # source makes it synchronous) and can overlap the engine working on another stream
+                pin = torch.empty(a.shape, dtype=torch.uint8, pin_memory=True)
+                pin.numpy()[...] = a
+                t = pin.to(dev, non_blocking=True)
+                keep.append(pin)
             keep.append(t)
             self._check(self.lib.mnx_preprocess(self.h, _ptr(t), t.shape[0], t.shape[1], pad, int(pad_to_square),
                                                 _ptr(crops[i]) if return_crops else None, _ptr(out[i]), _stream()),

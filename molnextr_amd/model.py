@@ -149,6 +149,7 @@ class molnextr:
                              dtype=dtype)
         self.input_size = args.input_size
         self.device_preprocess = device_preprocess
+        self.group_images = 1024          # images per engine call of the throughput path (whole reference batches)
 
     @staticmethod
     def _get_args(args_states=None):
@@ -170,6 +171,39 @@ class molnextr:
             return self.engine.preprocess(images)
         return torch.from_numpy(np.stack([transform_image(im, self.input_size) for im in images])).to(self.device)
 
+    def _prefetched(self, groups: List[List]):
+        """Yields the transformed tensor of every group; group g+1 is uploaded (pinned staging -> H2D) and transformed on a
+        side stream by a helper thread while the caller runs the engine on group g (reference main.py gets the same
+        overlap from DataLoader workers + pin_memory). `mnx_preprocess` is the one entry point that may run beside
+        another call on the same handle (include/molnextr_hip.h)."""
+        if len(groups) <= 1 or not self.device_preprocess:
+            for g in groups:
+                yield self._transform(g)
+            return
+        import threading
+        side = torch.cuda.Stream(device=self.device)
+
+        def work(g, box):
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(side):
+                    box.append(self._transform(g))          # Engine.preprocess synchronises `side` before returning
+            except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
+                box.append(e)
+
+        box: list = []
+        t = threading.Thread(target=work, args=(groups[0], box), daemon=True)
+        t.start()
+        for gi in range(len(groups)):
+            t.join()
+            item = box.pop()
+            if isinstance(item, BaseException):
+                raise item
+            if gi + 1 < len(groups):
+                box = []
+                t = threading.Thread(target=work, args=(groups[gi + 1], box), daemon=True)
+                t.start()
+            yield item
+
     def predict_images(self, input_images: List, return_atoms_bonds=False, return_confidence=False, batch_size=16):
         preds: List[dict] = []
         if len(input_images) == 0:
@@ -183,9 +217,9 @@ class molnextr:
         if not return_confidence:
             # throughput path: many images per engine call, reference batches of `batch_size` kept as numbering units;
             # the group is a whole number of reference batches so that batch boundaries do not drift between groups
-            group = (1024 // batch_size) * batch_size
-            for i in range(0, len(input_images), group):
-                x = self._transform(input_images[i:i + group])
+            group = (self.group_images // batch_size) * batch_size
+            groups = [input_images[i:i + group] for i in range(0, len(input_images), group)]
+            for x in self._prefetched(groups):
                 preds += predict_pipeline(self.engine, x, self.tokenizer, ref_batch_size=batch_size)
         else:
             step = max(self.engine.max_batch // batch_size, 1) * batch_size

@@ -504,6 +504,22 @@ def test_pipeline_facade_equals_per_batch_facade(eng, dev):
         assert x == y
 
 
+def test_facade_uploads_the_next_group_while_the_engine_works(dev):
+    """predict_images on host pages in several engine calls: group g+1 is uploaded (pinned staging) and transformed by
+    mnx_preprocess on a side stream / helper thread while mnx_predict runs group g. The results must be those of the
+    single-call path image by image (groups are whole reference batches, so the numbering does not change)."""
+    from molnextr_amd.model import molnextr
+    m = molnextr("synthetic", dev, max_batch=8)
+    pages = [W.synthetic_page(c) for c in range(11)] + [np.full((90, 130, 3), 255, np.uint8)]
+    for i, p in enumerate(pages[-1:]):
+        p[30:60, 20 + i:100] = 0
+    one = m.predict_images(pages, return_atoms_bonds=True, batch_size=4)
+    m.group_images = 4                                   # 3 engine calls, two of them overlapped with an upload
+    many = m.predict_images(pages, return_atoms_bonds=True, batch_size=4)
+    assert len(one) == len(many) == 12 and one == many
+    m.engine.close()
+
+
 def test_public_api_predict_images_synthetic(dev):
     """molnextr('synthetic').predict_images: reference output dict keys; no RDKit here -> SMILES fields None."""
     from molnextr_amd.model import molnextr, BOND_TYPES
