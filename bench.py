@@ -278,7 +278,7 @@ def main():
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
                 traffic_src = f"profiles/{name} (separate rocprofv3 --pmc passes over the same encoder launches)"
                 break
-        roofline = {"kernel": "mnx::gemm_tn_* (bf16 MFMA 16x16x32, all encoder Linear layers)",
+        roofline = {"kernel": "mnx::gemm_tn_* + mnx::gemm256_kernel (bf16 MFMA 16x16x32, all encoder Linear layers)",
                     "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb)),
