@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNX_ABI_VERSION 3
+#define MNX_ABI_VERSION 4
 
 typedef struct mnx_engine mnx_engine;
 
@@ -195,6 +195,18 @@ int mnx_atom_scan(mnx_engine* h, const int32_t* tokens, const int32_t* lengths, 
 int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t max_len,
                 int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx,
                 uint8_t* edges, int32_t kmax, void* stream);
+
+/* mnx_predict with beam search (BASELINE config 5): the same inputs and outputs, every reference batch decoded by
+ * mnx_decode_beam (n_best = 1: the best hypothesis; atom positions and the bond head run on ITS tokens and decoder
+ * outputs) while the encoder of the following launch groups runs on the second stream. Reference batches are searched
+ * one after the other (a beam step already carries ref_batch x beam rows); replaces `decoder.decode(features, hiddens,
+ * beam_size=beam)` inside the chunk loop of predict_images (MolNexTR/model.py:102-109, components.py:443) — a branch the
+ * reference itself cannot execute (see mnx_decode_beam).
+ *   scores    device fp32 [n_img]: average log-prob of the returned hypothesis
+ * Synchronous with respect to its outputs. */
+int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t beam, int32_t max_len,
+                     int32_t* tokens, int32_t* lengths, float* scores, int32_t* n_atoms, int32_t* atom_idx,
+                     uint8_t* edges, int32_t kmax, void* stream);
 
 /* Kernel-level timing aid for bench.py: runs the 16-bit MFMA GEMM of the encoder on caller buffers.
  * C[M,N] = A[M,K] . W[N,K]^T + bias, A/W 16-bit device, epi: 0 bias->16-bit, 1 bias+GELU->16-bit,

@@ -59,6 +59,7 @@ struct mnx_engine {
     float* out_trace = nullptr;
     BeamBuffers beam{};        // allocated lazily on the first mnx_decode_beam
     int* prep_bbox = nullptr;  // scratch of mnx_preprocess
+    float* beam_hidden = nullptr;   // mnx_predict_beam: [32, max_len, dec_dim] decoder outputs of the winners (lazy)
     int* host_flag = nullptr;  // pinned: [2][1 + MAX_CHUNKS] poll snapshots + slot lists
     std::map<GraphKey, hipGraphExec_t> graphs;
     // continuous-batching pipeline (mnx_predict)
@@ -756,6 +757,84 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
     }
     if (rc != MNX_OK) return rc;
     HIPCHK(h, beam_enqueue_gather(h->db, run, max_len, tokens, lengths, scores, hidden, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return MNX_OK;
+}
+
+int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t beam, int32_t max_len,
+                     int32_t* tokens, int32_t* lengths, float* scores, int32_t* n_atoms, int32_t* atom_idx,
+                     uint8_t* edges, int32_t kmax, void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!images || !tokens || !lengths || !scores || !n_atoms || !atom_idx || !edges || n_img < 1) {
+        h->err = "mnx_predict_beam: null/empty argument";
+        return MNX_ERR_INVALID_ARG;
+    }
+    if (!h->have_tc) { h->err = "mnx_predict_beam: call mnx_set_token_classes first"; return MNX_ERR_INVALID_ARG; }
+    const mnx_config& c = h->cfg;
+    if (ref_batch < 1 || ref_batch > ROW_TILE || ref_batch > c.max_batch || beam < 1 || beam > MAX_BEAM || max_len < 1 ||
+        max_len > c.max_len || kmax < 1 || kmax > h->db.kmax) {
+        h->err = "mnx_predict_beam: ref_batch <= min(32, max_batch), beam <= 8, max_len <= cfg.max_len, kmax <= cfg.max_atoms required";
+        return MNX_ERR_CAPACITY;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!s) {
+        if (!h->own_stream) HIPCHK(h, hipStreamCreate(&h->own_stream));
+        s = h->own_stream;
+    }
+    const int S = h->db.S, D = c.dec_dim;
+    const size_t img_elems = (size_t)3 * c.img_size * c.img_size;
+    if (!h->beam_hidden) {      // decoder outputs along the winning hypothesis of one reference batch
+        const size_t bytes = (size_t)ROW_TILE * c.max_len * D * 4;
+        HIPCHK(h, hipMalloc((void**)&h->beam_hidden, bytes));
+        h->allocs.push_back(h->beam_hidden);
+        h->bytes += bytes;
+    }
+    struct ExitGuard {          // every exit path: nothing of this call may still be in flight
+        mnx_engine* h; hipStream_t s;
+        ~ExitGuard() { (void)hipStreamSynchronize(h->enc_stream); (void)hipStreamSynchronize(s); }
+    } exit_guard{h, s};
+    // the encoder stream must not start before the caller's stream reaches this point (images ready)
+    HIPCHK(h, hipEventRecord(h->ev_poll[0], s));
+    HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_poll[0], 0));
+    const int n_chunks = (n_img + ref_batch - 1) / ref_batch;
+    const int grp = std::max(1, c.max_batch / ref_batch);      // reference batches per encoder launch group
+    int fb_first[2] = {-1, -1}, fb_count[2] = {0, 0};
+    bool feat_used[2] = {false, false};
+    int next_enc = 0;
+    for (int ck = 0; ck < n_chunks; ++ck) {
+        // keep both feature buffers busy on the encoder stream: the encoder of the following groups runs while the
+        // beam search of this reference batch occupies the caller's stream
+        for (int fb = 0; fb < 2; ++fb) {
+            if (fb_first[fb] >= 0 || next_enc >= n_chunks) continue;
+            const int cnt = std::min(grp, n_chunks - next_enc);
+            const int first = next_enc * ref_batch, n = std::min(cnt * ref_batch, n_img - first);
+            if (feat_used[fb]) HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_feat_free[fb], 0));
+            const int rc = mnx_encode(h, images + (size_t)first * img_elems, n, h->feat_ring[fb], h->enc_stream);
+            if (rc != MNX_OK) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_enc_done[fb], h->enc_stream));
+            fb_first[fb] = next_enc; fb_count[fb] = cnt; next_enc += cnt;
+        }
+        int fb = -1;
+        for (int i = 0; i < 2; ++i)
+            if (fb_first[i] >= 0 && ck >= fb_first[i] && ck < fb_first[i] + fb_count[i]) fb = i;
+        if (fb < 0) { h->err = "mnx_predict_beam: internal: reference batch without features"; return MNX_ERR_HIP; }
+        const int first = ck * ref_batch, n = std::min(ref_batch, n_img - first);
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_enc_done[fb], 0));
+        const float* feats = h->feat_ring[fb] + (size_t)(ck - fb_first[fb]) * ref_batch * S * h->dw.enc_dim;
+        int32_t* tok = tokens + (size_t)first * max_len;
+        int rc = mnx_decode_beam(h, feats, n, beam, 1, max_len, tok, lengths + first, scores + first, h->beam_hidden, s);
+        if (rc != MNX_OK) return rc;
+        if (ck + 1 == fb_first[fb] + fb_count[fb]) {     // last reference batch of the group: the buffer is free again
+            HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
+            feat_used[fb] = true;
+            fb_first[fb] = -1;
+        }
+        int32_t* aidx = atom_idx + (size_t)first * kmax;
+        HIPCHK(h, atoms_enqueue_raw(h->tc_dev, tok, lengths + first, n, max_len, kmax, aidx, n_atoms + first, s));
+        HIPCHK(h, edges_enqueue(h->dw, h->db, h->beam_hidden, nullptr, aidx, n_atoms + first, n, kmax, max_len,
+                                edges + (size_t)first * kmax * kmax, nullptr, s));
+    }
     HIPCHK(h, hipStreamSynchronize(s));
     return MNX_OK;
 }

@@ -18,11 +18,11 @@ from . import weights as W
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmolnextr_hip.so")
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
            "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess",
-           "mnx_probe_decode_attn")
+           "mnx_probe_decode_attn", "mnx_predict_beam")
 
 
 class MnxConfig(C.Structure):
@@ -92,6 +92,8 @@ def load_library():
     lib.mnx_decode_beam.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.mnx_predict.restype = C.c_int
     lib.mnx_predict.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
+    lib.mnx_predict_beam.restype = C.c_int
+    lib.mnx_predict_beam.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     if lib.mnx_abi_version() != ABI_VERSION:
         raise ImportError(f"libmolnextr_hip.so ABI {lib.mnx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
     _lib = lib
@@ -292,17 +294,26 @@ class Engine:
 
     # -- whole path, continuous batching ----------------------------------------------------------
     def predict(self, images: torch.Tensor, ref_batch: int = 32, max_len: Optional[int] = None,
-                stop_on_eos: bool = True) -> dict:
-        """Encoder + greedy decode + atom positions + bond head for all images (mnx_predict)."""
+                stop_on_eos: bool = True, beam: int = 1) -> dict:
+        """Encoder + decode + atom positions + bond head for all images: greedy with continuous batching (mnx_predict),
+        or beam search reference batch by reference batch with the encoder running ahead (mnx_predict_beam; adds
+        'scores', the average log-prob of the returned hypothesis)."""
         assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
         n = images.shape[0]
         max_len = self.max_len if max_len is None else max_len
         dev, k = images.device, self.max_atoms
-        tokens = torch.empty(n, max_len, dtype=torch.int32, device=dev)
+        tokens = torch.zeros(n, max_len, dtype=torch.int32, device=dev)
         lengths = torch.empty(n, dtype=torch.int32, device=dev)
         n_atoms = torch.empty(n, dtype=torch.int32, device=dev)
         atom_idx = torch.zeros(n, k, dtype=torch.int32, device=dev)
         edges = torch.zeros(n, k, k, dtype=torch.uint8, device=dev)
+        if beam > 1:
+            scores = torch.zeros(n, dtype=torch.float32, device=dev)
+            rc = self.lib.mnx_predict_beam(self.h, _ptr(images), n, ref_batch, beam, max_len, _ptr(tokens), _ptr(lengths),
+                                           _ptr(scores), _ptr(n_atoms), _ptr(atom_idx), _ptr(edges), k, _stream())
+            self._check(rc, "mnx_predict_beam")
+            return {"tokens": tokens, "lengths": lengths, "n_atoms": n_atoms, "atom_idx": atom_idx, "edges": edges,
+                    "scores": scores}
         rc = self.lib.mnx_predict(self.h, _ptr(images), n, ref_batch, max_len, int(stop_on_eos), _ptr(tokens), _ptr(lengths),
                                   _ptr(n_atoms), _ptr(atom_idx), _ptr(edges), k, _stream())
         self._check(rc, "mnx_predict")

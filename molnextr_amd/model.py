@@ -98,12 +98,14 @@ def decode_batch(engine: Engine, features: torch.Tensor, tokenizer=None, ref_bat
 
 
 def predict_pipeline(engine: Engine, images: torch.Tensor, tokenizer=None, ref_batch_size: int = 16,
-                     max_len: Optional[int] = None) -> List[dict]:
+                     max_len: Optional[int] = None, beam_size: int = 1) -> List[dict]:
     """Encoder + Decoder.decode for MANY images through the engine's continuous-batching path (mnx_predict):
     same per-image dicts as `decode_batch`, identical results (the on-device atom scan equals
-    sequence_to_smiles' indices), much higher throughput. Confidences are not available on this path."""
+    sequence_to_smiles' indices), much higher throughput. Confidences are not available on this path.
+    beam_size > 1: mnx_predict_beam (best hypothesis per image, 'beam_scores' = [its average log-prob])."""
     tok = (tokenizer or get_tokenizer())["chartok_coords"]
-    out = engine.predict(images, ref_batch=ref_batch_size, max_len=max_len)
+    out = engine.predict(images, ref_batch=ref_batch_size, max_len=max_len, beam=beam_size)
+    scores = out["scores"].cpu().numpy() if beam_size > 1 else None
     lens = out["lengths"].cpu().numpy()
     toks = out["tokens"].cpu().numpy()
     n_atoms = out["n_atoms"].cpu().numpy()
@@ -114,6 +116,8 @@ def predict_pipeline(engine: Engine, images: torch.Tensor, tokenizer=None, ref_b
         k = int(n_atoms[b])
         assert k == len(r["indices"]), "device atom scan disagrees with the host tokenizer"
         preds.append({"chartok_coords": r, "edges": edges[b, :k, :k].astype(int).tolist()})
+        if scores is not None:
+            preds[-1]["beam_scores"] = [float(scores[b])]
     return preds
 
 

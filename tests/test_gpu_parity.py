@@ -504,6 +504,22 @@ def test_pipeline_facade_equals_per_batch_facade(eng, dev):
         assert x == y
 
 
+def test_predict_beam_pipeline_equals_per_batch_beam(eng, dev):
+    """mnx_predict_beam (encoder running ahead on its own stream, beam search batch by batch, device atom scan and bond
+    head on the winner) must give exactly what encode + mnx_decode_beam + host atom positions + mnx_edges give per
+    reference batch — 40 images as reference batches of 16 (two full, one ragged), beam 5."""
+    from molnextr_amd.model import decode_batch, predict_pipeline
+    imgs = W.synthetic_images(40, first_index=300).to(dev)
+    a = predict_pipeline(eng, imgs, ref_batch_size=16, max_len=96, beam_size=5)
+    b = []
+    for i in range(0, 40, 16):
+        b += decode_batch(eng, eng.encode(imgs[i:i + 16].contiguous()), ref_batch_size=16, max_len=96, beam_size=5)
+    assert len(a) == len(b) == 40
+    for x, y in zip(a, b):
+        assert x["chartok_coords"] == y["chartok_coords"] and x["edges"] == y["edges"]
+        assert abs(x["beam_scores"][0] - y["beam_scores"][0]) < 1e-6
+
+
 def test_facade_uploads_the_next_group_while_the_engine_works(dev):
     """predict_images on host pages in several engine calls: group g+1 is uploaded (pinned staging) and transformed by
     mnx_preprocess on a side stream / helper thread while mnx_predict runs group g. The results must be those of the
