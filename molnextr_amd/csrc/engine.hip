@@ -49,11 +49,8 @@ struct mnx_engine {
     // encoder
     float *pe_wt = nullptr, *pe_b = nullptr, *pe_g = nullptr, *pe_beta = nullptr, *fn_g = nullptr, *fn_b = nullptr;
     std::vector<StageW> stages;
-    // encoder workspace, one set per encoder stream of mnx_predict (set 0 is also mnx_encode's)
-    struct EncWs {
-        float *xa = nullptr, *xb = nullptr;              // fp32 residual stream ping-pong
-        void *xn16 = nullptr, *qkv16 = nullptr, *attn16 = nullptr, *h16 = nullptr;
-    } ews[2];
+    float *xa = nullptr, *xb = nullptr;              // fp32 residual stream ping-pong
+    void *xn16 = nullptr, *qkv16 = nullptr, *attn16 = nullptr, *h16 = nullptr;
     int tap_item = -1;
     float* tap_dst = nullptr;
     // decoder
@@ -66,11 +63,7 @@ struct mnx_engine {
     int* host_flag = nullptr;  // pinned: [2][1 + MAX_CHUNKS] poll snapshots + slot lists
     std::map<GraphKey, hipGraphExec_t> graphs;
     // continuous-batching pipeline (mnx_predict)
-    hipStream_t enc_stream = nullptr, enc_stream2 = nullptr;
-    // mnx_predict alternates its encoder launch groups between two high-priority streams (one workspace each): the
-    // tail of one group's kernels (last round of a persistent GEMM, HBM-bound LayerNorm) is filled by the other group's;
-    // measured +2.1 % on the 20-step bench, no change at 256 steps
-    static constexpr int enc_streams = 2;
+    hipStream_t enc_stream = nullptr;
     hipEvent_t ev_order = nullptr;
     float* feat_ring[2] = {nullptr, nullptr};
     hipEvent_t ev_enc_done[2] = {nullptr, nullptr}, ev_feat_free[2] = {nullptr, nullptr}, ev_poll[2] = {nullptr, nullptr};
@@ -221,7 +214,6 @@ void mnx_destroy(mnx_engine* h) {
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     if (h->enc_stream) hipStreamDestroy(h->enc_stream);
-    if (h->enc_stream2) hipStreamDestroy(h->enc_stream2);
     if (h->ev_order) hipEventDestroy(h->ev_order);
     for (int i = 0; i < 2; ++i) {
         if (h->ev_enc_done[i]) hipEventDestroy(h->ev_enc_done[i]);
@@ -452,16 +444,13 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
             if (s + 1 < c.n_stages) { Ls /= 4; Cs *= 2; }
         }
     }
+    h->xa = (float*)P.dalloc(MB * L0 * C0 * 4);
+    h->xb = (float*)P.dalloc(MB * L0 * C0 * 4 / 2);
     const size_t es = dt_size(c.compute_dtype);     // operand element size: 2 (bf16 / fp16) or 4 (fp32 parity mode)
-    for (int w = 0; w < h->enc_streams; ++w) {
-        mnx_engine::EncWs& ws = h->ews[w];
-        ws.xa = (float*)P.dalloc(MB * L0 * C0 * 4);
-        ws.xb = (float*)P.dalloc(MB * L0 * C0 * 4 / 2);
-        ws.xn16 = P.dalloc(MB * max_xn * es);
-        ws.qkv16 = P.dalloc(MB * max_qkv * es);
-        ws.attn16 = P.dalloc(MB * max_xn * es);
-        ws.h16 = P.dalloc(MB * max_h * es);
-    }
+    h->xn16 = P.dalloc(MB * max_xn * es);
+    h->qkv16 = P.dalloc(MB * max_qkv * es);
+    h->attn16 = P.dalloc(MB * max_xn * es);
+    h->h16 = P.dalloc(MB * max_h * es);
     DecBuffers& db = h->db;
     const int SL = c.dec_slots > 0 ? c.dec_slots : 2048;
     h->n_chunk_bufs = SL / ROW_TILE;   // one reference batch per 32-slot row tile
@@ -496,7 +485,6 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&h->enc_stream, hipStreamNonBlocking, hi) != hipSuccess) P.problems.push_back("stream create failed");
-        if (hipStreamCreateWithPriority(&h->enc_stream2, hipStreamNonBlocking, hi) != hipSuccess) P.problems.push_back("stream create failed");
         if (hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) != hipSuccess) P.problems.push_back("event create failed");
     }
     for (int i = 0; i < 2; ++i)
@@ -530,13 +518,7 @@ int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst) {
     return MNX_OK;
 }
 
-static int encode_ws(mnx_engine* h, int wsi, const float* images, int32_t B, float* features_out, void* stream);
-
 int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_out, void* stream) {
-    return encode_ws(h, 0, images, B, features_out, stream);
-}
-
-static int encode_ws(mnx_engine* h, int wsi, const float* images, int32_t B, float* features_out, void* stream) {
     if (!h) return MNX_ERR_INVALID_ARG;
     if (!images || !features_out || B < 1) { h->err = "mnx_encode: null/empty argument"; return MNX_ERR_INVALID_ARG; }
     if (B > h->cfg.max_batch) { h->err = "mnx_encode: B exceeds max_batch"; return MNX_ERR_CAPACITY; }
@@ -545,9 +527,8 @@ static int encode_ws(mnx_engine* h, int wsi, const float* images, int32_t B, flo
     const int dt = c.compute_dtype;
     HIPCHK(h, hipSetDevice(h->device));
     int Hh = c.img_size / c.patch, Ww = Hh, C = c.embed_dim;
-    const mnx_engine::EncWs& ws = h->ews[wsi];
-    float* cur = ws.xa;
-    float* other = ws.xb;
+    float* cur = h->xa;
+    float* other = h->xb;
     int item = 0;
     auto tap = [&](size_t elems) -> hipError_t {
         hipError_t e = hipSuccess;
@@ -595,19 +576,19 @@ static int encode_ws(mnx_engine* h, int wsi, const float* images, int32_t B, flo
         for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
             const BlockW& w = st.blocks[bi];
             const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
-            HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, ws.xn16, nullptr, M, C));
-            HIPCHK(h, gemm(EPI_BIAS_16, ws.xn16, w.qkv_w, ws.qkv16, w.qkv_b, nullptr, M, 3 * C, C));
+            HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C));
+            HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, w.qkv_w, h->qkv16, w.qkv_b, nullptr, M, 3 * C, C));
             HIPCHK(h, timed(2, (double)M * C * 4.0 * es,
-                            [&]() { return launch_window_attn(dt, ws.qkv16, w.table, ws.attn16, B, Hh, Ww, C, st.heads, shift, s); }));
-            HIPCHK(h, gemm(EPI_RESID_F32, ws.attn16, w.proj_w, cur, w.proj_b, cur, M, C, C));
-            HIPCHK(h, ln(cur, w.ln2_g, w.ln2_b, ws.xn16, nullptr, M, C));
-            HIPCHK(h, gemm(EPI_GELU_16, ws.xn16, w.fc1_w, ws.h16, w.fc1_b, nullptr, M, 4 * C, C));
-            HIPCHK(h, gemm(EPI_RESID_F32, ws.h16, w.fc2_w, cur, w.fc2_b, cur, M, C, 4 * C));
+                            [&]() { return launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s); }));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, w.proj_w, cur, w.proj_b, cur, M, C, C));
+            HIPCHK(h, ln(cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C));
+            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, w.fc1_w, h->h16, w.fc1_b, nullptr, M, 4 * C, C));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->h16, w.fc2_w, cur, w.fc2_b, cur, M, C, 4 * C));
             HIPCHK(h, tap((size_t)M * C));
         }
         if (si + 1 < c.n_stages) {
-            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, ws.xn16, B, Hh, Ww, C, 1e-5f, s));
-            HIPCHK(h, gemm(EPI_BIAS_F32, ws.xn16, st.m_w, other, nullptr, nullptr, M / 4, 2 * C, 4 * C));
+            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s));
+            HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, st.m_w, other, nullptr, nullptr, M / 4, 2 * C, 4 * C));
             std::swap(cur, other);
             Hh /= 2; Ww /= 2; C *= 2;
             HIPCHK(h, tap((size_t)B * Hh * Ww * C));
@@ -942,8 +923,6 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     // the encoder stream must not start before the caller's stream reaches this point (images ready)
     HIPCHK(h, hipEventRecord(h->ev_poll[0], s));
     HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_poll[0], 0));
-    HIPCHK(h, hipStreamWaitEvent(h->enc_stream2, h->ev_poll[0], 0));
-    hipStream_t enc_s[2] = {h->enc_stream, h->enc_streams > 1 ? h->enc_stream2 : h->enc_stream};
     int next = 0, done = 0, seq = 0;
     const char* trace_path = getenv("MNX_TRACE");
     FILE* tf = trace_path ? fopen(trace_path, "a") : nullptr;
@@ -951,7 +930,6 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         mnx_engine* h; hipStream_t s; FILE*& tf;
         ~ExitGuard() {
             (void)hipStreamSynchronize(h->enc_stream);
-            (void)hipStreamSynchronize(h->enc_stream2);
             (void)hipStreamSynchronize(s);
             if (tf) { fclose(tf); tf = nullptr; }
         }
@@ -972,10 +950,10 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             if (fb_first[fb] >= 0 || next_enc >= n_chunks) continue;
             const int cnt = std::min(grp, n_chunks - next_enc);
             const int first = next_enc * ref_batch, n = std::min(cnt * ref_batch, n_img - first);
-            if (feat_used[fb]) HIPCHK(h, hipStreamWaitEvent(enc_s[fb], h->ev_feat_free[fb], 0));
-            rc = encode_ws(h, h->enc_streams > 1 ? fb : 0, images + (size_t)first * img_elems, n, h->feat_ring[fb], enc_s[fb]);
+            if (feat_used[fb]) HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_feat_free[fb], 0));
+            rc = mnx_encode(h, images + (size_t)first * img_elems, n, h->feat_ring[fb], h->enc_stream);
             if (rc != MNX_OK) return rc;
-            HIPCHK(h, hipEventRecord(h->ev_enc_done[fb], enc_s[fb]));
+            HIPCHK(h, hipEventRecord(h->ev_enc_done[fb], h->enc_stream));
             fb_first[fb] = next_enc;
             fb_count[fb] = cnt;
             next_enc += cnt;

@@ -1,12 +1,15 @@
 #!/bin/bash
-# scratch: A/B of one vs two encoder streams
+# scratch: rocprofv3 trace of the default (512-step) bench -> tick profile at steady state
 cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-for n in 1 2 1 2; do
-  MNX_ENC_STREAMS=$n timeout 300 python bench.py --steps 20 --warmup 5 --no-sub --no-cpu-baseline > gpurun_out/bench_es$n.log 2>&1
-  echo "enc_streams=$n rc=$? $(tail -1 gpurun_out/bench_es$n.log | grep -o '"value": [0-9.]*')"
-done
-MNX_ENC_STREAMS=2 timeout 300 python bench.py --steps 256 --warmup 16 --no-sub --no-cpu-baseline > gpurun_out/bench_es2_256.log 2>&1; echo "2 streams, 256 steps: $(tail -1 gpurun_out/bench_es2_256.log | grep -o '"value": [0-9.]*')"
-MNX_ENC_STREAMS=1 timeout 300 python bench.py --steps 256 --warmup 16 --no-sub --no-cpu-baseline > gpurun_out/bench_es1_256.log 2>&1; echo "1 stream, 256 steps: $(tail -1 gpurun_out/bench_es1_256.log | grep -o '"value": [0-9.]*')"
-MNX_ENC_STREAMS=2 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "pipeline or grouped or neighbouring or reproducible" > gpurun_out/t_es2.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/t_es2.log
+cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_def -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sub > $GRAFT_REPO_ROOT/gpurun_out/prof_def.log 2>&1
+cd $GRAFT_REPO_ROOT
+DB=$(find gpurun_out/prof_def -name "*.db" | head -1)
+ls -la $DB
+python tools/tick_profile.py $DB gpurun_out/tick_profile_default.txt > /dev/null
+python tools/rocpd_stats.py $DB gpurun_out/kernel_stats_default.txt | head -24
+rm -f $DB
+head -16 gpurun_out/tick_profile_default.txt
+grep -n "tick at rows_cap" -A51 gpurun_out/tick_profile_default.txt | tail -52 | head -20
+tail -1 gpurun_out/prof_def.log | cut -c1-200
