@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--beam", type=int, default=1, help="beam size; > 1 times BASELINE config 5 (one batch at a time)")
     ap.add_argument("--max-len", type=int, default=480)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "64")),
+    ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "128")),
                     help="images per encoder launch group (a multiple of 32; decode batches stay 32)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MNX_SLOTS", "3072")),
                     help="sequences resident in the decoder (multiple of 32, <= 4096)")

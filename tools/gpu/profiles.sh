@@ -7,13 +7,13 @@ export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-sub --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1
 echo "stats rc=$?"
-BATCH=64 ENCODES=2 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o enc -- python $R/tools/encode_once.py > $R/gpurun_out/pmc_fetch.log 2>&1
+BATCH=128 ENCODES=2 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o enc -- python $R/tools/encode_once.py > $R/gpurun_out/pmc_fetch.log 2>&1
 echo "fetch rc=$?"
-BATCH=64 ENCODES=2 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o enc -- python $R/tools/encode_once.py > $R/gpurun_out/pmc_write.log 2>&1
+BATCH=128 ENCODES=2 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o enc -- python $R/tools/encode_once.py > $R/gpurun_out/pmc_write.log 2>&1
 echo "write rc=$?"
 cd $R
 F=$(find gpurun_out/pmc_fetch -name "*.db" | head -1); W=$(find gpurun_out/pmc_write -name "*.db" | head -1)
-python tools/collect_traffic.py $F $W gpurun_out/r02_gemm_traffic_b64.json 64
+python tools/collect_traffic.py $F $W gpurun_out/r02_gemm_traffic_b128.json 128
 DB=$(find gpurun_out/prof_stats -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB gpurun_out/r02_kernel_stats_bench20.txt | head -12
 ls gpurun_out/prof_stats/*/ 2>/dev/null | head; find gpurun_out/prof_stats -name "*stats*" | head
