@@ -4,7 +4,7 @@
 // reference's precision): SURVEY K6-K12.
 //
 // One decode step = 8 small kernels per layer + 1 "head" kernel, all reading the step index from device memory
-// so the whole step is a fixed hipGraph that the host replays (engine.cpp). Batch rows are fixed slots; a
+// so the whole step is a fixed hipGraph that the host replays (engine.hip). Batch rows are fixed slots; a
 // finished row keeps its slot (no compaction on device) and the reference's row renumbering is emulated only
 // where it is observable: the positional-encoding row (see embed prologue).
 #include <stdlib.h>
