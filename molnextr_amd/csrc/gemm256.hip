@@ -121,6 +121,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 
     // bias of the tile being accumulated: 4 x 4 columns per lane, loaded by inline asm so that the loads are retired by
     // the counted waits of the main loop (a compiler-tracked load would drain the whole ring at its first use)
+    // (the compiler believes b4 is valid right after the asm statement: nothing may read or copy it before the waits of
+    //  the following K-tile have retired the loads — its only readers are in the epilogue, many waits later; the
+    //  all-element test tests/test_gpu_parity.py::test_gemm_persistent_256_tile_kernel guards this against a compiler
+    //  that would split the live range)
     f32x4 b4[4];
     auto load_bias = [&](int n0) {
         const float* bp = bias + n0 + wc * 64 + fg * 4;
