@@ -4,8 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no torchrun environment: bench.py launches itself under `python -m torch.distributed.run
+--nproc-per-node N` (one rank per GPU over RCCL); in every case the run FAILS unless the number of ranks equals --gpus
+and the node has that many GPUs — it never prints an `n_gpus` it did not use.
+
 One "step" = one pass of the whole hot path over one batch of 32 synthetic 384x384x3 images per GPU, inputs already
-resident in HBM: Swin-B encode (bf16 MFMA GEMMs) -> enc_transform + cross-KV -> greedy decode until EOS / 480 tokens
+resident in HBM: Swin-B encode (MFMA GEMMs; default operand mode fp16x3 = split fp16 operands, three 16-bit MFMA terms
+per product, fp32 accumulate: the fastest mode whose tokens / atoms / bonds equal the reference's from pixels) ->
+enc_transform + cross-KV -> greedy decode until EOS / 480 tokens
 (reference default max_length) -> on-device atom positions -> bond head; with N > 1 the batch of N*32 images is sharded
 by image across the ranks and the fixed-size result records are all-gathered with RCCL inside the timed region.
 Weights: deterministic synthetic checkpoint in the reference's exact state-dict layout (no pretrained checkpoint
@@ -15,24 +21,29 @@ the decoder at once and finished rows are refilled with the next batch. `--beam 
 (beam 5 x batch 32 through mnx_predict_beam: reference batches searched one after the other, encoder running ahead).
 
 Rank 0 prints ONE JSON line (contract in the task statement). Beyond the contract it carries
-  roofline        the dominant FLOP kernel (encoder GEMMs, bf16 MFMA): algorithmic FLOP (2*M*N*K per launch) divided by
+  roofline        the dominant FLOP kernel (encoder GEMMs, 16-bit MFMA): ALGORITHMIC FLOP (2*M*N*K per launch) divided by
                   event-bracketed durations measured LIVE on the encoder stream inside the timed region (at most 4 encoder
                   launch groups are bracketed, whatever --steps is); `isolated` = the same launches replayed afterwards;
-                  peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md)
+                  peak = 2500 TFLOP/s dense bf16 / fp16 (MI355X_MICROARCH.md). In the split modes the matrix pipe executes
+                  3 MFMA terms per algorithmic product: `mfma_terms` = 3 and `frac_of_peak_executed` = 3 x frac.
+                  `stage34` = the same figures for the block Linears of Swin stages 3 and 4 (C >= 512, the MFMA-bound shapes)
   roofline_extra  HBM-bound kernel classes: LayerNorm / window attention / patch embedding (live, same events) and the
                   two per-row decode attention kernels (isolated probe at a fixed operating point): algorithmic bytes /
                   duration against 8 TB/s
   sub_results     (N = 1 only, after the timed region) latency mode (one batch of 32 at a time), fixed-T=128 decode
-                  (deterministic work), fp32 parity mode throughput, beam 5 x batch 32
+                  (deterministic work), beam 5 x batch 32, and the throughput of the plain bf16 operand mode (fastest,
+                  not token-exact) next to the default mode's
   cpu_baseline    the CPU oracle (oracle/, bit-equal to the reference in the build container) on a bounded sample of
-                  the same workload on this box's host cores: best thread count, B in {1, 8}, encoder / decoder split,
-                  median of 3 after a warm-up, and a 1-thread figure
+                  the same workload on this box's host cores: thread sweep, B in {1, 32}, encoder /
+                  decoder split, natural and fixed-T=128 decode, median of 3 after a warm-up, 1-thread figure, lscpu model
   parity_note     what "SMILES exact-match" can mean here (RDKit is not installable: token SMILES + atom / bond sets).
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -66,74 +77,156 @@ def run_batch(eng, images, kmax, max_len, beam=1):
     return tokens, lengths, atom_idx, n_atoms, edges
 
 
-def gemm_algorithmic_bytes(batch=BATCH):
+def gemm_algorithmic_bytes(batch=BATCH, planes=1):
     """Average algorithmic HBM bytes per encoder GEMM launch (A + W read once, output written once, residual read
-    for the two residual epilogues) for Swin-B @384: the figure `roofline.traffic` is compared with."""
+    for the two residual epilogues) for Swin-B @384: the figure `roofline.traffic` is compared with. planes = 2 for
+    the split modes (every 16-bit operand / output is a hi and a lo plane)."""
     total, launches = 0, 0
     for s, (L, C, depth) in enumerate([(9216, 128, 2), (2304, 256, 2), (576, 512, 18), (144, 1024, 2)]):
         M = batch * L
-        per_block = [(M, 3 * C, C, 2, 0), (M, C, C, 4, 4), (M, 4 * C, C, 2, 0), (M, C, 4 * C, 4, 4)]
+        e16 = 2 * planes
+        per_block = [(M, 3 * C, C, e16, 0), (M, C, C, 4, 4), (M, 4 * C, C, e16, 0), (M, C, 4 * C, 4, 4)]
         for (m, n, k, out_b, res_b) in per_block:
-            total += depth * (m * k * 2 + n * k * 2 + m * n * (out_b + res_b))
+            total += depth * (m * k * e16 + n * k * e16 + m * n * (out_b + res_b))
             launches += depth
         if s < 3:
-            total += (M // 4) * 4 * C * 2 + 2 * C * 4 * C * 2 + (M // 4) * 2 * C * 4
+            total += (M // 4) * 4 * C * e16 + 2 * C * 4 * C * e16 + (M // 4) * 2 * C * 4
             launches += 1
     return total / launches
 
 
-def cpu_baseline(ck, budget_s=55.0):
-    """The CPU oracle on host cores: B = 1 with all threads (warm-up + median of 3, encoder / decoder
-    split), B = 8 at two thread counts (the best one is `value`), and a 1-thread B = 1 figure."""
+def host_cpu_info():
+    """lscpu model string, sockets x cores (physical), logical CPUs."""
+    info = {"model": None, "physical_cores": None, "logical_cpus": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for line in txt.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["model"] = kv.get("Model name")
+        info["physical_cores"] = int(kv.get("Socket(s)", "1")) * int(kv.get("Core(s) per socket", "0")) or None
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(ck, budget_s=85.0):
+    """The CPU oracle on host cores, as BASELINE.md section 3 plans it: thread-count sweep (encoder, B = 8), then at the
+    best count B = 32 (warm + median of 3: encoder, natural greedy decode + bond head) and B = 1, a fixed-T = 128 decode,
+    and a 1-thread B = 1 figure. Bounded: every leg checks the remaining budget."""
     from oracle.decoder import greedy_decode
     from oracle.edges import predict_edges
     from oracle.swin import encoder_forward
     tok = get_tokenizer()["chartok_coords"]
     t_start = time.time()
-    all_threads = torch.get_num_threads()
+    left = lambda: budget_s - (time.time() - t_start)   # noqa: E731
+    host = host_cpu_info()
+    logical = os.cpu_count() or 1
+    phys = host["physical_cores"] or max(1, logical // 2)
 
-    def one(img):
+    def enc(img):
         t0 = time.time()
         f = encoder_forward(img, ck["encoder"])
-        t1 = time.time()
-        g = greedy_decode(f, ck["decoder"])
-        for b in range(img.shape[0]):
+        return f, time.time() - t0
+
+    def dec(f, fixed_T=None):
+        t0 = time.time()
+        g = greedy_decode(f, ck["decoder"], max_len=fixed_T, stop_on_eos=fixed_T is None)
+        for b in range(f.shape[0]):
             idx = tok.sequence_to_smiles(g.tokens[b])["indices"]
             if idx:
                 predict_edges(g.hidden[b], idx, ck["decoder"])
-        t2 = time.time()
-        return t1 - t0, t2 - t1, [len(t) for t in g.tokens]
+        return time.time() - t0, [len(t) for t in g.tokens]
 
-    rows = []
-    img1, img8 = W.synthetic_images(1), W.synthetic_images(8)
-    one(img1)                                                     # warm-up
-    runs = []
-    while len(runs) < 3 and (time.time() - t_start) < budget_s * 0.35:
-        runs.append(one(img1))
-    if runs:
-        enc = statistics.median(r[0] for r in runs)
-        dec = statistics.median(r[1] for r in runs)
-        rows.append({"B": 1, "threads": all_threads, "runs": len(runs), "encoder_s": round(enc, 3), "decode_s": round(dec, 3),
-                     "molecules_per_s": round(1.0 / (enc + dec), 3), "decoded_len": runs[0][2]})
-    for th in sorted({all_threads, min(16, all_threads)}, reverse=True):
-        if (time.time() - t_start) > budget_s * 0.8:
+    img32 = W.synthetic_images(32)
+    img8, img1 = img32[:8].contiguous(), img32[:1].contiguous()
+    sweep = []
+    counts = sorted({c for c in (16, 32, 64, phys) if 1 <= c <= logical})
+    torch.set_num_threads(counts[0])
+    enc(img1)                                                         # warm-up (allocator, thread pool)
+    for th in counts:
+        if left() < budget_s * 0.75:
             break
         torch.set_num_threads(th)
-        e, d, lens = one(img8)
-        rows.append({"B": 8, "threads": th, "runs": 1, "encoder_s": round(e, 3), "decode_s": round(d, 3),
-                     "molecules_per_s": round(8.0 / (e + d), 3), "decoded_len_mean": round(float(np.mean(lens)), 1)})
-    if (time.time() - t_start) < budget_s:
+        _, t = enc(img8)
+        sweep.append({"threads": th, "B": 8, "encoder_s": round(t, 3), "images_per_s": round(8.0 / t, 2)})
+    best_th = max(sweep, key=lambda r: r["images_per_s"])["threads"] if sweep else min(16, logical)
+    torch.set_num_threads(best_th)
+    rows = []
+    runs = []
+    while len(runs) < 3 and left() > budget_s * 0.3:
+        f, te = enc(img32)
+        td, lens = dec(f)
+        runs.append((te, td, lens))
+    if runs:
+        te = statistics.median(r[0] for r in runs)
+        td = statistics.median(r[1] for r in runs)
+        lens = runs[0][2]
+        rows.append({"B": 32, "threads": best_th, "runs": len(runs), "mode": "natural (EOS / 480)", "encoder_s": round(te, 3),
+                     "decode_and_bonds_s": round(td, 3), "molecules_per_s": round(32.0 / (te + td), 3),
+                     "decoded_len_mean": round(float(np.mean(lens)), 1), "decoded_len_max": int(max(lens))})
+        if left() > 6:
+            tdf, _ = dec(f, fixed_T=128)
+            rows.append({"B": 32, "threads": best_th, "runs": 1, "mode": "fixed T = 128 (EOS ignored)", "encoder_s": round(te, 3),
+                         "decode_and_bonds_s": round(tdf, 3), "molecules_per_s": round(32.0 / (te + tdf), 3),
+                         "decode_ms_per_step": round(tdf / 128 * 1e3, 2)})
+    runs1 = []
+    while len(runs1) < 3 and left() > 8:
+        f, te = enc(img1)
+        td, lens = dec(f)
+        runs1.append((te, td))
+    if runs1:
+        te = statistics.median(r[0] for r in runs1)
+        td = statistics.median(r[1] for r in runs1)
+        rows.append({"B": 1, "threads": best_th, "runs": len(runs1), "mode": "natural (EOS / 480)", "encoder_s": round(te, 3),
+                     "decode_and_bonds_s": round(td, 3), "molecules_per_s": round(1.0 / (te + td), 3)})
+    if left() > 8:
         torch.set_num_threads(1)
-        e, d, lens = one(img1)
-        rows.append({"B": 1, "threads": 1, "runs": 1, "encoder_s": round(e, 3), "decode_s": round(d, 3),
-                     "molecules_per_s": round(1.0 / (e + d), 3)})
-    torch.set_num_threads(all_threads)
-    best = max(rows, key=lambda r: r["molecules_per_s"])
+        f, te = enc(img1)
+        td, _ = dec(f)
+        rows.append({"B": 1, "threads": 1, "runs": 1, "mode": "natural (EOS / 480)", "encoder_s": round(te, 3),
+                     "decode_and_bonds_s": round(td, 3), "molecules_per_s": round(1.0 / (te + td), 3)})
+    torch.set_num_threads(logical)
+    nat = [r for r in rows if r["mode"].startswith("natural")]
+    best = max(nat, key=lambda r: r["molecules_per_s"]) if nat else {"molecules_per_s": None, "threads": best_th, "B": 0}
     return {"value": best["molecules_per_s"], "unit": "molecules/s", "cores": best["threads"], "kind": "port",
-            "sample": f"CPU oracle (fp32 torch ops): synthetic images 0..{best['B'] - 1} as one reference batch, encoder + greedy "
-                      f"decode to EOS + bond head; best of the configurations in `runs` ({time.time() - t_start:.0f} s of CPU work, "
-                      f"host has {os.cpu_count()} logical CPUs)",
-            "runs": rows}
+            "sample": (f"CPU oracle (fp32 torch ops, bit-equal to the reference in the build container): synthetic images "
+                       f"0..{best['B'] - 1} as one reference batch, encoder + greedy decode to EOS + bond head, median of the runs "
+                       f"listed; thread count chosen by the encoder sweep ({time.time() - t_start:.0f} s of CPU work)"),
+            "host": host, "thread_sweep": sweep, "runs": rows}
+
+
+def plan_launch(gpus, env, device_count):
+    """What `python bench.py --gpus N` must do, decided before anything touches a GPU:
+      ("run", world)    run in this process as one of `world` ranks (world == gpus is enforced),
+      ("spawn", None)   no torchrun environment and gpus > 1: launch the N ranks ourselves.
+    Raises SystemExit with a clear message when the request cannot be honoured (fewer GPUs than asked for, or a torchrun
+    world size that differs from --gpus): a line that says n_gpus N must have used N."""
+    if gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if device_count < gpus:
+        raise SystemExit(f"bench.py --gpus {gpus}: this node exposes {device_count} GPU(s); refusing to report n_gpus={gpus} "
+                         "from fewer devices")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"bench.py --gpus {gpus} was started with WORLD_SIZE={world}: ranks and --gpus must agree")
+        return "run", world
+    return ("spawn", None) if gpus > 1 else ("run", 1)
+
+
+def spawn_ranks(gpus, argv):
+    """Re-executes this script under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -144,7 +237,8 @@ def main():
     ap.add_argument("--mode", default="pipeline", choices=["pipeline", "batch"])
     ap.add_argument("--beam", type=int, default=1, help="beam size; > 1 times BASELINE config 5 (one batch at a time)")
     ap.add_argument("--max-len", type=int, default=480)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp16x3", choices=["fp16x3", "bf16x3", "bf16", "fp16", "fp32"],
+                    help="encoder operand mode; fp16x3 (default) is the fastest one that is token-exact vs the reference")
     ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "128")),
                     help="images per encoder launch group (a multiple of 32; decode batches stay 32)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MNX_SLOTS", "3072")),
@@ -154,13 +248,15 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL record gather even with one rank")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if args.steps < 1:
         raise SystemExit("--steps must be >= 1")
+    action, world = plan_launch(args.gpus, os.environ, torch.cuda.device_count())
+    if action == "spawn":
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or ("RANK" in os.environ and args.force_gather)
@@ -169,6 +265,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     rccl_ranks = dist.get_world_size() if use_dist else 1
+    if rccl_ranks != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the process group has {rccl_ranks} rank(s)")
     from molnextr_amd.engine import Engine
 
     mode = "beam" if args.beam > 1 else args.mode
@@ -265,32 +363,59 @@ def main():
             eng.encode(imgs[i * eb:(i + 1) * eb].contiguous())
         iso = eng.profile_read_all()
         eng.profile(False)
-        src = live_prof if (live_prof and live_prof["gemm"][2] > 0) else iso
-        gemm_ms, gemm_flop, launches = src["gemm"]
-        iso_ms, iso_flop, iso_n = iso["gemm"]
+        split = args.dtype in ("fp16x3", "bf16x3")
+        terms = 3 if split else 1
+
+        def family(prof, kinds):
+            ms = sum(prof[k][0] for k in kinds)
+            fl = sum(prof[k][1] for k in kinds)
+            n = sum(prof[k][2] for k in kinds)
+            return ms, fl, n
+
+        have_live = bool(live_prof) and (live_prof["gemm"][2] + live_prof["gemm_s34"][2]) > 0
+        src = live_prof if have_live else iso
+        gemm_ms, gemm_flop, launches = family(src, ("gemm", "gemm_s34"))
+        iso_ms, iso_flop, iso_n = family(iso, ("gemm", "gemm_s34"))
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         isolated = iso_flop / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
+        s_ms, s_flop, s_n = family(src, ("gemm_s34",))
+        si_ms, si_flop, si_n = family(iso, ("gemm_s34",))
+        s34 = s_flop / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
+        s34_iso = si_flop / (si_ms * 1e-3) / 1e12 if si_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        for name in (f"r02_gemm_traffic_b{eb}.json", f"r01_gemm_traffic_b{eb}.json"):
+        for name in (f"r03_gemm_traffic_{args.dtype}_b{eb}.json", f"r02_gemm_traffic_b{eb}.json"):
+            if name.startswith("r02") and args.dtype != "bf16":
+                continue
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_traffic.py)
                 with open(tpath) as f:
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
                 traffic_src = f"profiles/{name} (separate rocprofv3 --pmc passes over the same encoder launches)"
                 break
-        roofline = {"kernel": "mnx::gemm_tn_* + mnx::gemm256_kernel (bf16 MFMA 16x16x32, all encoder Linear layers)",
+        mfma = {"fp16x3": "v_mfma_f32_16x16x32_f16 x 3 terms", "bf16x3": "v_mfma_f32_16x16x32_bf16 x 3 terms",
+                "bf16": "v_mfma_f32_16x16x32_bf16", "fp16": "v_mfma_f32_16x16x32_f16", "fp32": "v_mfma_f32_16x16x4_f32"}[args.dtype]
+        roofline = {"kernel": f"mnx::gemm_tn_* + mnx::gemm256_kernel ({mfma}, all encoder Linear layers)",
                     "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb)),
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                    "work": "algorithmic FLOP = 2*M*N*K per launch",
+                    "mfma_terms": terms, "frac_of_peak_executed": round(terms * achieved / PEAK_BF16_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb, 2 if split else 1)),
                     "images_per_launch": eb,
                     "launches": int(launches), "avg_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
                     "flop_per_launch_avg": round(gemm_flop / max(launches, 1)),
                     "measured": ("live: HIP events on the encoder stream inside the timed region (<= 4 launch groups)"
                                  if src is live_prof else "replay after the timed region"),
                     "isolated": {"achieved": round(isolated, 1), "avg_launch_us": round(iso_ms * 1e3 / max(iso_n, 1), 2),
-                                 "launches": int(iso_n)}}
+                                 "launches": int(iso_n)},
+                    "stage34": {"what": "block Linears with C >= 512 (Swin-B stages 3 and 4: qkv / proj / fc1 / fc2, the MFMA-bound "
+                                        "shapes; north_star's >= 60 % target applies to these)",
+                                "achieved": round(s34, 1), "frac": round(s34 / PEAK_BF16_TFLOPS, 4),
+                                "frac_of_peak_executed": round(terms * s34 / PEAK_BF16_TFLOPS, 4), "launches": int(s_n),
+                                "avg_launch_us": round(s_ms * 1e3 / max(s_n, 1), 2),
+                                "isolated": {"achieved": round(s34_iso, 1), "frac": round(s34_iso / PEAK_BF16_TFLOPS, 4)}}}
         extra = []
-        for kind, label in (("layernorm", "mnx::layernorm16_kernel (fp32 in, 16-bit out)"),
+        for kind, label in (("layernorm", "mnx::layernorm16_kernel (fp32 in, 16-bit operand planes out)"),
                             ("window_attn", "mnx::window_attn_kernel (qkv in, context out)"),
                             ("patch_embed", "mnx::patch_embed_kernel")):
             for tag, prof in (("live", live_prof), ("isolated", iso)):
@@ -333,16 +458,17 @@ def main():
                                                 "mnx_predict_beam (batch by batch, the encoder running ahead on its own stream)",
                                         "ms_per_batch": round(t / 4 * 1e3, 2), "molecules_per_s": round(4 * BATCH / t, 1),
                                         "decoded_len_mean": round(float(np.mean(stats["lens"])), 1)}
-            if args.dtype != "fp32":
+            if args.dtype != "bf16" and args.beam == 1:
                 eng.close()
-                eng = Engine(ck["encoder"], ck["decoder"], device=local, max_batch=BATCH, dtype="fp32", dec_slots=1024)
-                ns = min(args.steps, 6)
-                x = images_for(0, ns)
-                process(eng, x[:BATCH].contiguous(), 1, "pipeline", land=False)
+                eng = Engine(ck["encoder"], ck["decoder"], device=local, max_batch=eb, dtype="bf16", dec_slots=args.slots)
+                ns = args.steps
+                x = images_for(args.warmup, ns)
+                process(eng, x[:min(ns, 8) * BATCH].contiguous(), min(ns, 8), "pipeline", land=False)
                 t = timed(lambda: process(eng, x, ns, "pipeline", land=False))
-                sub["parity_mode_fp32"] = {"what": f"{ns} steps with every encoder operand in fp32 (exact-fp32 MFMA): tokens / atoms / bonds "
-                                                   "equal the reference from pixels (tests/test_gpu_pixels.py)",
-                                           "molecules_per_s": round(ns * BATCH / t, 1)}
+                sub["throughput_mode_bf16"] = {"what": f"the same {ns} steps with plain bf16 encoder operands (one MFMA term per product): the fastest "
+                                                       "mode, NOT token-exact vs the reference (argmax near-ties flip: tests/test_gpu_pixels.py, "
+                                                       "profiles/r03_pixels_parity.json)",
+                                               "molecules_per_s": round(ns * BATCH / t, 1)}
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(ck)   # host baseline: rank 0 at N=1 only
         total = args.steps * BATCH * world
         if mode == "beam":
@@ -351,7 +477,7 @@ def main():
                         "encode + beam search (n_best 1) + atom positions + bond head on the best hypothesis")
         else:
             workload = ("batch=32 synthetic 384x384x3 images per GPU, synthetic_checkpoint(0) in the reference state-dict "
-                        "layout (no pretrained weights offline), Swin-B encode + greedy decode to EOS "
+                        f"layout (no pretrained weights offline), Swin-B encode ({args.dtype} operands) + greedy decode to EOS "
                         f"(max_length {args.max_len}) + atom positions + bond head"
                         + (", RCCL all-gather of result records" if world > 1 else ""))
         out = {
@@ -370,8 +496,10 @@ def main():
             "rccl_ranks": rccl_ranks,
             "roofline": roofline, "roofline_extra": extra, "sub_results": sub, "cpu_baseline": cpu,
             "parity_note": ("SMILES exact-match vs the reference is checked on the raw token SMILES + atom / bond sets (RDKit is not "
-                            "installable here): exact from pixels in fp32 parity mode; in the 16-bit operand modes argmax near-ties "
-                            "can flip (tests/test_gpu_pixels.py, DESIGN.md §6)"),
+                            "installable here). dtype fp16x3 (this line's default) and fp32: logits within 1e-3, every token / atom / "
+                            "bond equal to the reference from pixels (tests/test_gpu_pixels.py, 32 + 6 images, free-running and "
+                            "teacher-forced); bf16x3: logits within 1e-3, flips only on near-ties; plain bf16 / fp16: argmax near-ties "
+                            "flip (profiles/r03_pixels_parity.json, DESIGN.md §6)"),
         }
     eng.close()
     if use_dist:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNX_ABI_VERSION 4
+#define MNX_ABI_VERSION 5
 
 typedef struct mnx_engine mnx_engine;
 
@@ -35,14 +35,25 @@ typedef enum {
     MNX_ERR_WEIGHTS = -2,       /* a tensor of the weight contract is missing or has a wrong shape */
     MNX_ERR_HIP = -3,           /* a HIP runtime call failed (see mnx_last_error)                 */
     MNX_ERR_NO_DEVICE = -4,     /* no gfx950 device at the requested index                        */
-    MNX_ERR_CAPACITY = -5       /* batch / length / atom count exceeds what mnx_create reserved   */
+    MNX_ERR_CAPACITY = -5,      /* batch / length / atom count exceeds what mnx_create reserved   */
+    MNX_ERR_RANGE = -6          /* the encoder produced non-finite features (fp16 operand range)  */
 } mnx_status;
 
 /* Operand type of the encoder MFMA GEMMs / window attention (accumulation, residual stream, LayerNorm and softmax are
- * fp32 in every mode; the decoder and the bond head are fp32 always). FP32 is the parity mode: every encoder operand in
- * fp32 on the exact-fp32 matrix instructions (1/16 of the bf16 rate) — tokens / atoms / bonds equal the reference from
- * pixels; BF16 is the throughput mode north_star asks for (near-tie argmax decisions can differ). */
-enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1, MNX_DTYPE_FP32 = 2 };
+ * fp32 in every mode; the decoder and the bond head are fp32 always).
+ *   BF16, FP16     one 16-bit plane per operand: the fastest modes; the operand rounding (2^-9 / 2^-12 relative) reaches
+ *                  the logits as 6e-2 / 9e-3, so argmax decisions near a tie can differ from the reference;
+ *   FP16X3, BF16X3 split operands: every GEMM / attention operand v is carried as two 16-bit planes hi = T(v),
+ *                  lo = T(v - hi), every product evaluated as hi.hi + hi.lo + lo.hi on the 16-bit MFMA with fp32
+ *                  accumulation, exact-erf GELU. FP16X3 (weights stored scaled by a power of two per matrix so that their
+ *                  lo planes are normal numbers) reproduces the fp32 path to fp32 rounding level: tokens / atoms / bonds
+ *                  equal the reference from pixels at a third of the 16-bit MFMA rate. This is the default of the Python
+ *                  facade and of bench.py. Activations must stay inside the fp16 range (|v| < 65504): a non-finite
+ *                  encoder output is reported as MNX_ERR_RANGE by mnx_predict / mnx_predict_beam and by
+ *                  mnx_encoder_status; BF16X3 has the fp32 range and ~2^-16 relative product error;
+ *   FP32           every encoder operand in fp32 on the exact-fp32 matrix instructions (1/16 of the bf16 rate): the
+ *                  reference-arithmetic mode the split modes are checked against. */
+enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1, MNX_DTYPE_FP32 = 2, MNX_DTYPE_BF16X3 = 3, MNX_DTYPE_FP16X3 = 4 };
 
 /* Architecture + capacity. Defaults of the reference inference config are in the comments
  * (MolNexTR/models/transformers.py:547-551 swin_base; MolNexTR/model.py:50-81; MolNexTR/utils.py:25). */
@@ -65,7 +76,7 @@ typedef struct {
     int32_t max_len;         /* 480: decode capacity (FORMAT_INFO['chartok_coords']['max_len']) */
     int32_t max_batch;       /* images per mnx_encode call the workspace is sized for */
     int32_t max_atoms;       /* kmax of mnx_edges (<= max_len / 3) */
-    int32_t compute_dtype;   /* MNX_DTYPE_BF16 */
+    int32_t compute_dtype;   /* MNX_DTYPE_FP16X3 (fast AND reference-exact); MNX_DTYPE_BF16 = fastest */
     int32_t dec_slots;       /* sequences resident in the decoder during mnx_predict: multiple of 32, <= 4096; 0 = 2048 */
 } mnx_config;
 
@@ -103,6 +114,16 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
  * item < 0 disables. */
 int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst);
 
+/* Test / measurement aid for the split modes (compute_dtype BF16X3 / FP16X3): choose per op class whether its products
+ * are evaluated with all three terms (bit set, the default) or with the hi.hi term alone, i.e. as the plain 16-bit mode
+ * would. Bits: 1 qkv Linear, 2 window attention (QK^T and PV), 4 proj Linear, 8 fc1, 16 fc2, 32 patch-merging reduction.
+ * Used by tests/test_gpu_pixels.py to measure which op classes the feature error comes from. No effect in other modes. */
+int mnx_set_split_terms(mnx_engine* h, int32_t mask);
+
+/* Synchronises `stream` and reports (then clears) whether any mnx_encode since the last call produced a non-finite
+ * feature row — the only way the fp16 operand modes can fail on a checkpoint whose activations exceed 65504. */
+int mnx_encoder_status(mnx_engine* h, int32_t* nonfinite, void* stream);
+
 /* Replaces `TransformerDecoderAR.decode(beam_size=1)` (MolNexTR/components.py:253-334) including enc_transform
  * (:206-216), Embeddings with the batch-row positional-encoding quirk (MolNexTR/models/embedding.py:52-59),
  * TransformerDecoder stepwise forward (MolNexTR/models/decoder.py:431-486), output layer + log_softmax +
@@ -122,6 +143,17 @@ int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst);
  * Synchronous with respect to its outputs: returns after the last step has completed on `stream`. */
 int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
                       int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, float* token_logp, float* hidden,
+                      float* logits_trace, void* stream);
+
+/* Test aid: mnx_decode_greedy with TEACHER FORCING. Every row advances with forced_ids[b][t] (device int32 [B,max_len],
+ * an id sequence that ends with EOS or fills max_len — e.g. the reference's own output) instead of its own argmax, so
+ * the history, the finish steps and therefore the positional-encoding rows of the whole batch are the reference's at
+ * every step. Outputs: argmax_ids [B,max_len] = what this engine would have chosen at each step GIVEN the reference
+ * history; forced_logp [B,max_len] = masked log-prob it assigns to the forced id; lengths = steps taken; logits_trace as
+ * mnx_decode_greedy. tests/test_gpu_pixels.py uses it to measure the log-prob error of the 16-bit operand modes along
+ * the reference trajectory, free of knock-on effects, and to count argmax flips per token. */
+int mnx_decode_forced(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
+                      const int32_t* forced_ids, int32_t* argmax_ids, int32_t* lengths, float* forced_logp,
                       float* logits_trace, void* stream);
 
 /* Beam search over one reference batch — the `beam_size > 1` branch of TransformerDecoderAR.decode
@@ -214,13 +246,21 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
 int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C, const float* bias, int32_t M,
                int32_t N, int32_t K, void* stream);
 
+/* The same for the split modes (the engine's compute_dtype must be BF16X3 / FP16X3): A, W (and C for epi 0 / 1) point at
+ * hi planes, a_lo / w_lo / c_lo are the ELEMENT offsets of the lo planes, C = epi(oscale * (Ah.Wh + Ah.Wl + Al.Wh) + bias)
+ * with the exact-erf GELU; terms = 3, or 1 for Ah.Wh alone. */
+int mnx_gemm16_split(mnx_engine* h, int32_t epi, const void* A, int64_t a_lo, const void* W, int64_t w_lo, float oscale,
+                     void* C, int64_t c_lo, const float* bias, int32_t M, int32_t N, int32_t K, int32_t terms,
+                     void* stream);
+
 /* Measurement aid for bench.py: while enabled, mnx_encode brackets every kernel launch of the sampled calls with a
  * pair of HIP events recorded on the stream the kernel is launched on (also inside mnx_predict, i.e. live in a timed
  * region). `enable` = n > 0: every n-th mnx_encode call since the enable is sampled, at most 4 calls (the event pool
  * stays small and is reused; the launches of the other calls run un-bracketed). mnx_profile_read synchronises and
  * returns, for one kernel class, the totals accumulated since the last reset: summed event-to-event milliseconds,
  * algorithmic work and launch count.
- *   kind 0  MFMA GEMM             work = FLOP (2*M*N*K per launch)
+ *   kind 0  MFMA GEMM             work = FLOP (2*M*N*K per launch): stages with C < 512 and the patch-merging reductions
+ *   kind 4  MFMA GEMM             the same for the block Linears with C >= 512 (Swin-B stages 3 and 4: the MFMA-bound shapes)
  *   kind 1  LayerNorm             work = HBM bytes (fp32 in, operand-type out [+ fp32 out])
  *   kind 2  window attention      work = HBM bytes (qkv in, context out)
  *   kind 3  patch embedding       work = HBM bytes (image in, fp32 tokens out)

@@ -45,6 +45,20 @@ template <> struct H16<float> {
     }
 };
 
+// Split-operand modes (kernels.h MNX_DT_BF16X3 / MNX_DT_F16X3): v = hi + lo up to 2^-22 |v| (fp16; the lo plane may be
+// subnormal, the MFMA does not flush 16-bit inputs) or 2^-17 |v| (bf16).
+template <typename T>
+__device__ __forceinline__ void split16(float v, T& hi, T& lo) {
+    hi = (T)v;
+    lo = (T)(v - (float)hi);
+}
+template <typename T>
+__device__ __forceinline__ void split16x4(f32x4 v, typename H16<T>::v4& hi, typename H16<T>::v4& lo) {
+    hi = (typename H16<T>::v4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+    lo = (typename H16<T>::v4){(T)(v[0] - (float)hi[0]), (T)(v[1] - (float)hi[1]), (T)(v[2] - (float)hi[2]),
+                               (T)(v[3] - (float)hi[3])};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -62,7 +76,8 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // GELU for 16-bit outputs (encoder MLP) on the packed fp32 pipe. x * Phi(x) with
 // Phi(x) = 0.5 + xc * Q(u), xc = clamp(x, -5, 5), u = 2 xc^2 / 25 - 1, Q = degree-12 Chebyshev fit of (Phi(x) - 0.5) / x
 // converted to monomials in u (sum |coef| = 0.4, so fp32 Horner is well conditioned). |error| <= 2.3e-6 absolute over the
-// reals (checked against scipy erf in float32, tests/test_device_math.py), far below the bf16/fp16 rounding of the stored result.
+// reals (checked against scipy erf in float32, tests/test_device_math.py), far below the bf16/fp16 rounding of the stored result;
+// the outer factor is max(x, -5) so that the tail x < -5 stays at -5 Phi(-5) = -1.4e-6 instead of growing with |x|.
 // 9 full-rate VALU operations per value instead of the 12 + two quarter-rate transcendentals (rcp, exp2) of an
 // exp-based erf: the GELU epilogue of fc1 was VALU-bound. The fp32 parity mode uses erff.
 // Four values per call: the two packed chains are independent, so back-to-back dependent packed operations (which cost a
@@ -86,7 +101,9 @@ __device__ __forceinline__ f32x4 gelu_fast4(f32x4 x) {
     q = q * u + 5.151792988e-02f;
     q = q * u + -7.029590756e-02f;
     q = q * u + 1.413638145e-01f;
-    return x * (xc * q + 0.5f);
+    f32x4 xo;
+    xo[0] = fmaxf(x[0], -5.0f); xo[1] = fmaxf(x[1], -5.0f); xo[2] = fmaxf(x[2], -5.0f); xo[3] = fmaxf(x[3], -5.0f);
+    return xo * (xc * q + 0.5f);
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast4((f32x4){x, x, x, x})[0]; }
 

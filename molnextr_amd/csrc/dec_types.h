@@ -107,8 +107,9 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
                              int mem_blk0, int max_len, int stop_on_eos, hipStream_t s);
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s);
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s);
+// forced: [trace_rows, T] ids or null — teacher forcing of slots 0..trace_rows-1 (test aid, see HeadArgs)
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
-                            int trace_rows, hipStream_t s, const BeamBuffers* beam = nullptr);
+                            int trace_rows, hipStream_t s, const BeamBuffers* beam = nullptr, const int* forced = nullptr);
 hipError_t beam_enqueue_init(const DecBuffers& b, const BeamBuffers& bm, int max_len, hipStream_t s);
 hipError_t beam_enqueue_gather(const DecBuffers& b, const BeamBuffers& bm, int out_len, int* o_tokens, int* o_len,
                                float* o_scores, float* o_hidden, hipStream_t s);

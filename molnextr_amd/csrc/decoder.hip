@@ -380,6 +380,9 @@ struct HeadArgs {
     float* hidden;         // [slots, T, 256]
     float* logits_trace;   // [T, trace_rows, V] or null (slots 0..trace_rows-1)
     float* blp;            // BEAM: [slots, BEAM_LP_STRIDE] masked log-probs out (the pick kernel chooses)
+    const int* forced;     // [trace_rows, T] or null. Teacher forcing (test aid, mnx_decode_forced): slot s < trace_rows
+                           // advances with forced[s][t] instead of its own argmax; tokens[] still records the argmax,
+                           // token_logp[] the masked log-prob of the FORCED id
     int V, VP, T, x0, y0, eos, trace_rows;
 };
 
@@ -451,15 +454,18 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __syncthreads();
     if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
     __syncthreads();
+    const int ftok = (a.forced && slot < a.trace_rows) ? a.forced[(size_t)slot * a.T + t] : -1;
+    if (ftok >= 0 && tid == ftok) a.token_logp[(size_t)slot * a.T + t] = lp;
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
         a.tokens[(size_t)slot * a.T + t] = bi;
-        a.token_logp[(size_t)slot * a.T + t] = bv;
-        a.st->prev_tok[slot] = bi;
+        if (ftok < 0) a.token_logp[(size_t)slot * a.T + t] = bv;
+        const int adv = ftok >= 0 ? ftok : bi;
+        a.st->prev_tok[slot] = adv;
         a.st->len[slot] = t + 1;
         a.st->t[slot] = t + 1;
-        if ((a.st->stop_on_eos[slot] && bi == a.eos) || t + 1 >= a.st->max_len[slot]) a.st->alive[slot] = 0;
+        if ((a.st->stop_on_eos[slot] && adv == a.eos) || t + 1 >= a.st->max_len[slot]) a.st->alive[slot] = 0;
     }
 }
 
@@ -565,7 +571,7 @@ __global__ void beam_begin_kernel(DecState* st, int B, int K);
 __global__ void beam_pick_kernel(DecState* st, BeamBuffers bm, const float* hidden, int* etok, int T, int V, int eos);
 
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
-                            int trace_rows, hipStream_t s, const BeamBuffers* beam) {
+                            int trace_rows, hipStream_t s, const BeamBuffers* beam, const int* forced) {
     // slots_scan: state slots the begin kernel scans; rows: capacity of the compact active list this tick is
     // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
     const int D = 256, H = w.heads, T = b.T;
@@ -616,7 +622,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
     h.x = b.x; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
-    h.eos = 2; h.trace_rows = trace_rows;
+    h.eos = 2; h.trace_rows = trace_rows; h.forced = forced;
     if (beam) {
         h.blp = beam->blp;
         hipLaunchKernelGGL(dec_head_kernel<true>, dim3(slots), dim3(256), 0, s, h);

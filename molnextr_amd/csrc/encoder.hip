@@ -89,11 +89,12 @@ hipError_t launch_patch_embed(const float* img, const float* w_t, const float* b
 //     MERGE=true fuses the PatchMerging 2x2 gather (reference transformers.py:325-333): logical row
 //     (b, y2, x2) is the concat of x[b, 2y2+dy, 2x2+dx, :] for (dy,dx) = (0,0),(1,0),(0,1),(1,1).
 // =============================================================================================
-template <typename T, bool MERGE, int NV>
+//     SPLIT (dtypes BF16X3 / F16X3): the 16-bit output is two planes, hi and lo = v - hi (y_lo elements behind).
+template <typename T, bool MERGE, int NV, bool SPLIT>
 __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ y16,
                                                           float* __restrict__ y32, int M, int C, float eps, int H,
-                                                          int W, int Cin) {
+                                                          int W, int Cin, size_t y_lo, int* __restrict__ flag) {
     typedef typename H16<T>::v4 v4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -135,6 +136,8 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restric
         }
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    // one non-finite input poisons mean and variance of the whole row: rstd is NaN (or 0 for an infinite variance)
+    if (flag && lane == 0 && !(rstd > 0.f && rstd < 3.0e38f)) atomicOr(flag, 1);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int e = lane * 4 + j * 256;
@@ -142,53 +145,62 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restric
             const f32x4 g = *(const f32x4*)(gamma + e), bt = *(const f32x4*)(beta + e);
             const f32x4 o = v[j] * rstd * g + bt;
             if (y16) {
-                v4 o4 = {(T)o[0], (T)o[1], (T)o[2], (T)o[3]};
-                *(v4*)(y16 + (size_t)row * C + e) = o4;
+                if (SPLIT) {
+                    v4 hi, lo;
+                    split16x4<T>(o, hi, lo);
+                    *(v4*)(y16 + (size_t)row * C + e) = hi;
+                    *(v4*)(y16 + y_lo + (size_t)row * C + e) = lo;
+                } else {
+                    v4 o4 = {(T)o[0], (T)o[1], (T)o[2], (T)o[3]};
+                    *(v4*)(y16 + (size_t)row * C + e) = o4;
+                }
             }
             if (y32) *(f32x4*)(y32 + (size_t)row * C + e) = o;
         }
     }
 }
 
-template <typename T, bool MERGE>
+template <typename T, bool MERGE, bool SPLIT>
 static void ln_dispatch(dim3 grid, hipStream_t s, const float* x, const float* gamma, const float* beta, T* y16,
-                        float* y32, int M, int C, float eps, int H, int W, int Cin) {
+                        float* y32, int M, int C, float eps, int H, int W, int Cin, size_t y_lo, int* flag) {
     dim3 block(256);
     if (C <= 256)
-        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 1>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 1, SPLIT>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin, y_lo, flag);
     else if (C <= 512)
-        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 2>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 2, SPLIT>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin, y_lo, flag);
     else if (C <= 1024)
-        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 4>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 4, SPLIT>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin, y_lo, flag);
     else
-        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 8>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin);
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 8, SPLIT>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin, y_lo, flag);
+}
+
+template <bool MERGE>
+static hipError_t ln_by_dtype(int dtype, dim3 grid, hipStream_t s, const float* x, const float* gamma, const float* beta,
+                              void* y16, float* y32, int M, int C, float eps, int H, int W, int Cin, size_t y_lo,
+                              int* flag) {
+    if (dt_split(dtype) && y16 && y_lo == 0) return hipErrorInvalidValue;
+    switch (dtype) {
+        case MNX_DT_F16: ln_dispatch<f16_t, MERGE, false>(grid, s, x, gamma, beta, (f16_t*)y16, y32, M, C, eps, H, W, Cin, 0, flag); break;
+        case MNX_DT_F32: ln_dispatch<float, MERGE, false>(grid, s, x, gamma, beta, (float*)y16, y32, M, C, eps, H, W, Cin, 0, flag); break;
+        case MNX_DT_BF16: ln_dispatch<bf16_t, MERGE, false>(grid, s, x, gamma, beta, (bf16_t*)y16, y32, M, C, eps, H, W, Cin, 0, flag); break;
+        case MNX_DT_F16X3: ln_dispatch<f16_t, MERGE, true>(grid, s, x, gamma, beta, (f16_t*)y16, y32, M, C, eps, H, W, Cin, y_lo, flag); break;
+        case MNX_DT_BF16X3: ln_dispatch<bf16_t, MERGE, true>(grid, s, x, gamma, beta, (bf16_t*)y16, y32, M, C, eps, H, W, Cin, y_lo, flag); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_layernorm16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, float* y32,
-                              int M, int C, float eps, hipStream_t s) {
+                              int M, int C, float eps, hipStream_t s, size_t y_lo, int* nonfinite_flag) {
     if (C > 2048 || (C & 3)) return hipErrorInvalidValue;
-    dim3 grid((M + 3) / 4);
-    if (dtype == MNX_DT_F16)
-        ln_dispatch<f16_t, false>(grid, s, x, gamma, beta, (f16_t*)y16, y32, M, C, eps, 0, 0, 0);
-    else if (dtype == MNX_DT_F32)
-        ln_dispatch<float, false>(grid, s, x, gamma, beta, (float*)y16, y32, M, C, eps, 0, 0, 0);
-    else
-        ln_dispatch<bf16_t, false>(grid, s, x, gamma, beta, (bf16_t*)y16, y32, M, C, eps, 0, 0, 0);
-    return hipGetLastError();
+    return ln_by_dtype<false>(dtype, dim3((M + 3) / 4), s, x, gamma, beta, y16, y32, M, C, eps, 0, 0, 0, y_lo, nonfinite_flag);
 }
 
 hipError_t launch_merge_ln16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, int B, int H,
-                             int W, int C, float eps, hipStream_t s) {
+                             int W, int C, float eps, hipStream_t s, size_t y_lo) {
     if (4 * C > 2048 || (C & 3) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
     const int M = B * (H / 2) * (W / 2);
-    dim3 grid((M + 3) / 4);
-    if (dtype == MNX_DT_F16)
-        ln_dispatch<f16_t, true>(grid, s, x, gamma, beta, (f16_t*)y16, nullptr, M, 4 * C, eps, H, W, C);
-    else if (dtype == MNX_DT_F32)
-        ln_dispatch<float, true>(grid, s, x, gamma, beta, (float*)y16, nullptr, M, 4 * C, eps, H, W, C);
-    else
-        ln_dispatch<bf16_t, true>(grid, s, x, gamma, beta, (bf16_t*)y16, nullptr, M, 4 * C, eps, H, W, C);
-    return hipGetLastError();
+    return ln_by_dtype<true>(dtype, dim3((M + 3) / 4), s, x, gamma, beta, y16, nullptr, M, 4 * C, eps, H, W, C, y_lo, nullptr);
 }
 
 template <typename T>
@@ -200,12 +212,30 @@ __global__ void cast16_kernel(const float* __restrict__ x, T* __restrict__ y, si
         *(v4*)(y + i * 4) = o;
     }
 }
+// split modes: hi = T(scale * x), lo = T(scale * x - hi); scale is a power of two (exact)
+template <typename T>
+__global__ void cast16_split_kernel(const float* __restrict__ x, T* __restrict__ y, size_t n4, size_t y_lo, float scale) {
+    typedef typename H16<T>::v4 v4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(x + i * 4) * scale;
+        v4 hi, lo;
+        split16x4<T>(v, hi, lo);
+        *(v4*)(y + i * 4) = hi;
+        *(v4*)(y + y_lo + i * 4) = lo;
+    }
+}
 
-hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStream_t s) {
+hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStream_t s, size_t y_lo, float scale) {
     if (n & 3) return hipErrorInvalidValue;
     const size_t n4 = n / 4;
     dim3 grid((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)), block(256);
-    if (dtype == MNX_DT_F16)
+    if (dt_split(dtype)) {
+        if (y_lo < n) return hipErrorInvalidValue;
+        if (dtype == MNX_DT_F16X3)
+            hipLaunchKernelGGL((cast16_split_kernel<f16_t>), grid, block, 0, s, x, (f16_t*)y16, n4, y_lo, scale);
+        else
+            hipLaunchKernelGGL((cast16_split_kernel<bf16_t>), grid, block, 0, s, x, (bf16_t*)y16, n4, y_lo, scale);
+    } else if (dtype == MNX_DT_F16)
         hipLaunchKernelGGL((cast16_kernel<f16_t>), grid, block, 0, s, x, (f16_t*)y16, n4);
     else if (dtype == MNX_DT_F32)
         hipLaunchKernelGGL((cast16_kernel<float>), grid, block, 0, s, x, (float*)y16, n4);
@@ -370,10 +400,161 @@ __global__ __launch_bounds__(576) void window_attn_kernel(const T* __restrict__ 
         }
 }
 
+// Split-operand form (dtypes BF16X3 / F16X3): q, k, v arrive as hi / lo planes, S = kh.qh + kh.ql + kl.qh and
+// O = vh.ph + vh.pl + vl.ph on the same MFMAs (small terms first), the context leaves as hi / lo planes. The
+// un-normalised probabilities are scaled by 2^10 before they are split (exp(s - max) <= 1 would put most lo parts into the
+// fp16 subnormal range); the scale cancels in O / sum. Same structure and index arithmetic as window_attn_kernel.
+template <typename T>
+__global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restrict__ qkv, size_t qkv_lo,
+                                                                const float* __restrict__ table, T* __restrict__ out,
+                                                                size_t out_lo, int H, int W, int C, int heads, int shift,
+                                                                int terms) {
+    constexpr int NTHR = 576;
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) T Ks[2][WN * KS_STRIDE];
+    __shared__ __attribute__((aligned(16))) T Vt[2][HD * VT_STRIDE];
+    __shared__ float tab[(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int rowof[WN];
+    __shared__ __attribute__((aligned(16))) int kinfo[WN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nWw = W / WS, nWh = H / WS;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = bid % heads; bid /= heads;
+    const int wx = bid % nWw; bid /= nWw;
+    const int wy = bid % nWh;
+    const int b = bid / nWh;
+
+    const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
+    for (int t = tid; t < WN; t += NTHR) {
+        const int ty = t / WS, tx = t % WS;
+        int ys = wy * WS + ty, xs = wx * WS + tx;
+        int yo = ys + shift; if (yo >= H) yo -= H;
+        int xo = xs + shift; if (xo >= W) xo -= W;
+        rowof[t] = (b * H + yo) * W + xo;
+        const int reg = (last_y ? (ty < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (tx < WS - shift ? 1 : 2) : 0);
+        kinfo[t] = (ty * (2 * WS - 1) + tx) | (reg << 16);
+    }
+    for (int i = tid; i < 529; i += NTHR) tab[i] = table[i * heads + head];
+    for (int i = tid; i < 2 * HD * (VT_STRIDE - WN); i += NTHR) {
+        const int pl = i / (HD * (VT_STRIDE - WN)), j = i % (HD * (VT_STRIDE - WN));
+        Vt[pl][(j / (VT_STRIDE - WN)) * VT_STRIDE + WN + j % (VT_STRIDE - WN)] = (T)0.f;
+    }
+    __syncthreads();
+
+    const size_t ld = (size_t)3 * C;
+    for (int i = tid; i < 2 * WN * 4; i += NTHR) {       // 576 16-byte chunks each for K and V, two planes
+        const int pl = i / (WN * 4), key = (i >> 2) % WN, g8 = i & 3;
+        const T* base = qkv + (pl ? qkv_lo : (size_t)0) + (size_t)rowof[key] * ld + head * HD + g8 * 8;
+        const v8 kv = *(const v8*)(base + C);
+        const v8 vv = *(const v8*)(base + 2 * C);
+        *(v8*)(Ks[pl] + key * KS_STRIDE + g8 * 8) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[pl][(g8 * 8 + j) * VT_STRIDE + key] = vv[j];
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qrow = rowof[wave * 16 + fr];
+    const v8 qh = *(const v8*)(qkv + (size_t)qrow * ld + head * HD + fg * 8);
+    const v8 ql = *(const v8*)(qkv + qkv_lo + (size_t)qrow * ld + head * HD + fg * 8);
+    __syncthreads();
+
+    const bool x3 = terms == 3;
+    f32x4 acc[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+        const v8 kh = *(const v8*)(Ks[0] + (kt * 16 + fr) * KS_STRIDE + fg * 8);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (x3) {
+            const v8 kl = *(const v8*)(Ks[1] + (kt * 16 + fr) * KS_STRIDE + fg * 8);
+            a = H16<T>::mfma(kl, qh, a);
+            a = H16<T>::mfma(kh, ql, a);
+        }
+        acc[kt] = H16<T>::mfma(kh, qh, a);
+    }
+
+    const float scale = 0.17677669529663687f;
+    const int qinfo = kinfo[wave * 16 + fr];
+    const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS);
+    const int rq = qinfo >> 16;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+        const int4 ki4 = *(const int4*)(kinfo + kt * 16 + fg * 4);
+        const int kis[4] = {ki4.x, ki4.y, ki4.z, ki4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sc = acc[kt][r] * scale + tab[qa - (kis[r] & 0xffff)];
+            if ((kis[r] >> 16) != rq) sc += -100.0f;
+            acc[kt][r] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = __expf(acc[kt][r] - mx) * 1024.0f;
+            acc[kt][r] = pv;
+            sum += pv;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv_sum = 1.0f / sum;
+
+    f32x4 oacc[2];
+    oacc[0] = oacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const f32x4 p0 = acc[2 * m];
+        const f32x4 p1 = (m < 4) ? acc[m < 4 ? 2 * m + 1 : 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        v4 h0, l0, h1, l1;
+        split16x4<T>(p0, h0, l0);
+        split16x4<T>(p1, h1, l1);
+        const v8 ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        const v8 pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const T* vrow = Vt[0] + (dt * 16 + fr) * VT_STRIDE + m * 32 + fg * 4;
+            const v4 a = *(const v4*)vrow, c = *(const v4*)(vrow + 16);
+            const v8 vh = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            if (x3) {
+                const T* vrl = Vt[1] + (dt * 16 + fr) * VT_STRIDE + m * 32 + fg * 4;
+                const v4 al = *(const v4*)vrl, cl = *(const v4*)(vrl + 16);
+                const v8 vl = {al[0], al[1], al[2], al[3], cl[0], cl[1], cl[2], cl[3]};
+                oacc[dt] = H16<T>::mfma(vl, ph, oacc[dt]);
+                oacc[dt] = H16<T>::mfma(vh, pl, oacc[dt]);
+            }
+            oacc[dt] = H16<T>::mfma(vh, ph, oacc[dt]);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        v4 hi, lo;
+        split16x4<T>(oacc[dt] * inv_sum, hi, lo);
+        const size_t o = (size_t)qrow * C + head * HD + dt * 16 + fg * 4;
+        *(v4*)(out + o) = hi;
+        *(v4*)(out + out_lo + o) = lo;
+    }
+}
+
 hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,
-                              int C, int heads, int shift, hipStream_t s) {
+                              int C, int heads, int shift, hipStream_t s, size_t qkv_lo, size_t out_lo, int terms) {
     if (C != heads * HD || H % WS || W % WS) return hipErrorInvalidValue;
     dim3 grid(B * (H / WS) * (W / WS) * heads);
+    if (dt_split(dtype)) {
+        if (qkv_lo == 0 || out_lo == 0 || (terms != 1 && terms != 3)) return hipErrorInvalidValue;
+        if (dtype == MNX_DT_F16X3)
+            hipLaunchKernelGGL((window_attn_split_kernel<f16_t>), grid, dim3(576), 0, s, (const f16_t*)qkv16, qkv_lo, rel_table,
+                               (f16_t*)out16, out_lo, H, W, C, heads, shift, terms);
+        else
+            hipLaunchKernelGGL((window_attn_split_kernel<bf16_t>), grid, dim3(576), 0, s, (const bf16_t*)qkv16, qkv_lo, rel_table,
+                               (bf16_t*)out16, out_lo, H, W, C, heads, shift, terms);
+        return hipGetLastError();
+    }
 #define MNX_ATTN(TT)                                                                                                  \
     hipLaunchKernelGGL((window_attn_kernel<TT>), grid, dim3(576), 0, s, (const TT*)qkv16, rel_table, (TT*)out16, H, W, \
                        C, heads, shift)

@@ -23,19 +23,30 @@ namespace {
 
 thread_local std::string g_create_error;   // message of the calling thread's last failed mnx_create
 
+// One GEMM weight in its operand form: a single 16-bit (or fp32) plane, or — split modes — a hi plane with the lo plane
+// `lo` elements behind it, both holding 2^k * W (k per matrix, fp16 split only); oscale = 2^-k.
+struct W16 {
+    void* p = nullptr;
+    size_t lo = 0;
+    float oscale = 1.f;
+};
 struct BlockW {
     float *ln1_g, *ln1_b, *table, *qkv_b, *proj_b, *ln2_g, *ln2_b, *fc1_b, *fc2_b;
-    void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    W16 qkv_w, proj_w, fc1_w, fc2_w;
 };
 struct StageW {
     std::vector<BlockW> blocks;
     float *m_g = nullptr, *m_b = nullptr;
-    void* m_w = nullptr;
+    W16 m_w;
     int C = 0, heads = 0;
 };
+// op classes of the split modes (mnx_set_split_terms)
+enum { SPL_QKV = 1, SPL_ATTN = 2, SPL_PROJ = 4, SPL_FC1 = 8, SPL_FC2 = 16, SPL_MERGE = 32, SPL_ALL = 63 };
 struct GraphKey {
-    int slots, rows, trace;
-    bool operator<(const GraphKey& o) const { return std::tie(slots, rows, trace) < std::tie(o.slots, o.rows, o.trace); }
+    int slots, rows, trace, forced;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(slots, rows, trace, forced) < std::tie(o.slots, o.rows, o.trace, o.forced);
+    }
 };
 
 }  // namespace
@@ -51,12 +62,16 @@ struct mnx_engine {
     std::vector<StageW> stages;
     float *xa = nullptr, *xb = nullptr;              // fp32 residual stream ping-pong
     void *xn16 = nullptr, *qkv16 = nullptr, *attn16 = nullptr, *h16 = nullptr;
+    size_t xn_lo = 0, qkv_lo = 0, attn_lo = 0, h_lo = 0;   // split modes: element offset of each buffer's lo plane
+    int split_mask = SPL_ALL;                               // op classes evaluated with all three product terms
+    int* enc_flag = nullptr;                                // device: set when the final LayerNorm sees a non-finite row
     int tap_item = -1;
     float* tap_dst = nullptr;
     // decoder
     DecWeights dw{};
     DecBuffers db{};
     float* out_trace = nullptr;
+    int* forced_ids = nullptr;  // [32, max_len] teacher-forcing ids of mnx_decode_forced (lazy; test aid)
     BeamBuffers beam{};        // allocated lazily on the first mnx_decode_beam
     int* prep_bbox = nullptr;  // scratch of mnx_preprocess
     float* beam_hidden = nullptr;   // mnx_predict_beam: [32, max_len, dec_dim] decoder outputs of the winners (lazy)
@@ -79,7 +94,7 @@ struct mnx_engine {
     int prof_calls = 0;        // ... counted since mnx_profile_enable
     int prof_groups = 0;       // encode calls bracketed so far (capped: the event pool stays small)
     int prof_max_groups = 4;
-    struct Ev { hipEvent_t a, b; double work; int kind; };   // kind 0 GEMM (work = FLOP), 1 LayerNorm, 2 window attention, 3 patch embed (work = algorithmic HBM bytes)
+    struct Ev { hipEvent_t a, b; double work; int kind; };   // kind 0 / 4 GEMM (work = FLOP; 4 = block Linears with C >= 512), 1 LayerNorm, 2 window attention, 3 patch embed (work = algorithmic HBM bytes)
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
 };
@@ -143,22 +158,39 @@ struct Packer {
         for (int64_t s : shape) n *= (size_t)s;
         return up32(d->data, n);
     }
-    void* w16(const std::string& name, std::initializer_list<int64_t> shape) {
+    W16 w16(const std::string& name, std::initializer_list<int64_t> shape) {
+        W16 w;
         const mnx_weight_desc* d = find(name, shape);
-        if (!d) return nullptr;
+        if (!d) return w;
         size_t n = 1;
         for (int64_t s : shape) n *= (size_t)s;
         if (n > staging_elems) {
             problems.push_back("staging too small for " + name);
-            return nullptr;
+            return w;
         }
-        void* p = dalloc(n * dt_size(h->cfg.compute_dtype));
-        if (!p) return nullptr;
+        const int dt = h->cfg.compute_dtype;
+        float scale = 1.f;
+        if (dt == MNX_DT_F16X3) {
+            // fp16 split: store 2^k W with max |2^k W| in [2^14, 2^15) — the lo plane of a weight of typical size
+            // (|w| ~ 0.02) would be subnormal otherwise; the GEMM epilogue multiplies by 2^-k (exact)
+            float mx = 0.f;
+            for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(d->data[i]));
+            if (mx > 0.f && std::isfinite(mx)) {
+                int e = 0;
+                std::frexp(mx, &e);                        // mx = f * 2^e, f in [0.5, 1)
+                const int k = std::min(60, std::max(-60, 15 - e));
+                scale = std::ldexp(1.f, k);
+            }
+        }
+        w.p = dalloc(n * dt_size(dt));
+        if (!w.p) return w;
+        w.lo = dt_split(dt) ? n : 0;
+        w.oscale = 1.f / scale;
         if (hipMemcpy(staging, d->data, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-            launch_cast16(h->cfg.compute_dtype, staging, p, n, 0) != hipSuccess ||
+            launch_cast16(dt, staging, w.p, n, 0, w.lo, scale) != hipSuccess ||
             hipStreamSynchronize(0) != hipSuccess)
             problems.push_back("convert failed for " + name);
-        return p;
+        return w;
     }
     const float* host(const std::string& name, std::initializer_list<int64_t> shape) {
         const mnx_weight_desc* d = find(name, shape);
@@ -191,8 +223,7 @@ int check_cfg(const mnx_config& c, std::string& why) {
     if (c.max_len < 1 || c.max_len > 512) return bad("max_len must be 1..512");
     if (c.max_batch < 1) return bad("max_batch < 1");
     if (c.max_atoms < 1 || c.max_atoms > 256) return bad("max_atoms must be 1..256");
-    if (c.compute_dtype != MNX_DTYPE_BF16 && c.compute_dtype != MNX_DTYPE_FP16 && c.compute_dtype != MNX_DTYPE_FP32)
-        return bad("compute_dtype");
+    if (c.compute_dtype < MNX_DTYPE_BF16 || c.compute_dtype > MNX_DTYPE_FP16X3) return bad("compute_dtype");
     if (c.dec_slots < 0 || c.dec_slots > MAX_SLOTS || (c.dec_slots % ROW_TILE) != 0) return bad("dec_slots");
     if (c.pe_len < ROW_TILE) return bad("pe_len too small");
     return MNX_OK;
@@ -446,11 +477,17 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     }
     h->xa = (float*)P.dalloc(MB * L0 * C0 * 4);
     h->xb = (float*)P.dalloc(MB * L0 * C0 * 4 / 2);
-    const size_t es = dt_size(c.compute_dtype);     // operand element size: 2 (bf16 / fp16) or 4 (fp32 parity mode)
+    // operand bytes per element: 2 (bf16 / fp16), 4 (fp32 parity mode, or the two 16-bit planes of the split modes)
+    const size_t es = dt_size(c.compute_dtype);
     h->xn16 = P.dalloc(MB * max_xn * es);
     h->qkv16 = P.dalloc(MB * max_qkv * es);
     h->attn16 = P.dalloc(MB * max_xn * es);
     h->h16 = P.dalloc(MB * max_h * es);
+    if (dt_split(c.compute_dtype)) {
+        h->xn_lo = MB * max_xn; h->qkv_lo = MB * max_qkv; h->attn_lo = MB * max_xn; h->h_lo = MB * max_h;
+    }
+    h->enc_flag = (int*)P.dalloc(sizeof(int));
+    if (h->enc_flag && hipMemset(h->enc_flag, 0, sizeof(int)) != hipSuccess) P.problems.push_back("hipMemset failed");
     DecBuffers& db = h->db;
     const int SL = c.dec_slots > 0 ? c.dec_slots : 2048;
     h->n_chunk_bufs = SL / ROW_TILE;   // one reference batch per 32-slot row tile
@@ -518,6 +555,38 @@ int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst) {
     return MNX_OK;
 }
 
+int mnx_set_split_terms(mnx_engine* h, int32_t mask) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (mask < 0 || mask > SPL_ALL) { h->err = "mnx_set_split_terms: mask must be 0..63"; return MNX_ERR_INVALID_ARG; }
+    h->split_mask = mask;
+    return MNX_OK;
+}
+
+int mnx_encoder_status(mnx_engine* h, int32_t* nonfinite, void* stream) {
+    if (!h || !nonfinite) return MNX_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(&flag, h->enc_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (flag) HIPCHK(h, hipMemsetAsync(h->enc_flag, 0, sizeof(int), s));
+    *nonfinite = flag;
+    return MNX_OK;
+}
+
+// mnx_predict / mnx_predict_beam: after the final synchronisation, turn a non-finite encoder output into an error
+static int check_encoder_range(mnx_engine* h, hipStream_t s) {
+    int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(&flag, h->enc_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (!flag) return MNX_OK;
+    HIPCHK(h, hipMemsetAsync(h->enc_flag, 0, sizeof(int), s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->err = "encoder features are not finite (an activation left the fp16 range of compute_dtype FP16 / FP16X3, or the "
+             "input holds NaN / Inf): use MNX_DTYPE_BF16X3 or MNX_DTYPE_FP32 for this checkpoint";
+    return MNX_ERR_RANGE;
+}
+
 int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_out, void* stream) {
     if (!h) return MNX_ERR_INVALID_ARG;
     if (!images || !features_out || B < 1) { h->err = "mnx_encode: null/empty argument"; return MNX_ERR_INVALID_ARG; }
@@ -558,14 +627,21 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         return hipEventRecord(ev.b, s);
     };
     const double es = (double)dt_size(dt);
-    auto gemm = [&](int epi, const void* A, const void* Wt, void* Cc, const float* bias, const float* resid, int M,
-                    int N, int K) -> hipError_t {
-        return timed(0, 2.0 * (double)M * (double)N * (double)K,
-                     [&]() { return launch_gemm16(dt, epi, A, Wt, Cc, bias, resid, M, N, K, s); });
+    const bool split = dt_split(dt);
+    // split modes: a_lo / c_lo = lo-plane offsets of the activation buffers, cls = the op class whose bit of split_mask
+    // selects three product terms (default) or the hi.hi term alone (error-budget aid)
+    auto gemm = [&](int epi, const void* A, size_t a_lo, const W16& Wt, void* Cc, size_t c_lo, const float* bias,
+                    const float* resid, int M, int N, int K, int cls) -> hipError_t {
+        SplitArgs sp;
+        sp.a_lo = a_lo; sp.w_lo = Wt.lo; sp.c_lo = c_lo; sp.oscale = Wt.oscale;
+        sp.terms = (h->split_mask & cls) ? 3 : 1;
+        // kind 4: the Linear layers of the blocks with C >= 512 (Swin-B stages 3 and 4, the MFMA-bound shapes); kind 0: the rest
+        return timed((cls != SPL_MERGE && std::min(N, K) >= 512) ? 4 : 0, 2.0 * (double)M * (double)N * (double)K,
+                     [&]() { return launch_gemm16(dt, epi, A, Wt.p, Cc, bias, resid, M, N, K, s, split ? &sp : nullptr); });
     };
     auto ln = [&](const float* x, const float* g, const float* b, void* y16, float* y32, int M, int Cc) -> hipError_t {
         return timed(1, (double)M * Cc * (4.0 + (y16 ? es : 0.0) + (y32 ? 4.0 : 0.0)),
-                     [&]() { return launch_layernorm16(dt, x, g, b, y16, y32, M, Cc, 1e-5f, s); });
+                     [&]() { return launch_layernorm16(dt, x, g, b, y16, y32, M, Cc, 1e-5f, s, h->xn_lo, y32 ? h->enc_flag : nullptr); });
     };
     HIPCHK(h, timed(3, (double)B * (3.0 * c.img_size * c.img_size + (double)Hh * Ww * C) * 4.0,
                     [&]() { return launch_patch_embed(images, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta, cur, B, c.img_size, C, s); }));
@@ -577,18 +653,20 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
             const BlockW& w = st.blocks[bi];
             const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
             HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C));
-            HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, w.qkv_w, h->qkv16, w.qkv_b, nullptr, M, 3 * C, C));
-            HIPCHK(h, timed(2, (double)M * C * 4.0 * es,
-                            [&]() { return launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s); }));
-            HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, w.proj_w, cur, w.proj_b, cur, M, C, C));
+            HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, h->xn_lo, w.qkv_w, h->qkv16, h->qkv_lo, w.qkv_b, nullptr, M, 3 * C, C, SPL_QKV));
+            HIPCHK(h, timed(2, (double)M * C * 4.0 * es, [&]() {
+                return launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s, h->qkv_lo,
+                                          h->attn_lo, (h->split_mask & SPL_ATTN) ? 3 : 1);
+            }));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, h->attn_lo, w.proj_w, cur, 0, w.proj_b, cur, M, C, C, SPL_PROJ));
             HIPCHK(h, ln(cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C));
-            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, w.fc1_w, h->h16, w.fc1_b, nullptr, M, 4 * C, C));
-            HIPCHK(h, gemm(EPI_RESID_F32, h->h16, w.fc2_w, cur, w.fc2_b, cur, M, C, 4 * C));
+            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, h->xn_lo, w.fc1_w, h->h16, h->h_lo, w.fc1_b, nullptr, M, 4 * C, C, SPL_FC1));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->h16, h->h_lo, w.fc2_w, cur, 0, w.fc2_b, cur, M, C, 4 * C, SPL_FC2));
             HIPCHK(h, tap((size_t)M * C));
         }
         if (si + 1 < c.n_stages) {
-            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s));
-            HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, st.m_w, other, nullptr, nullptr, M / 4, 2 * C, 4 * C));
+            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s, h->xn_lo));
+            HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, h->xn_lo, st.m_w, other, 0, nullptr, nullptr, M / 4, 2 * C, 4 * C, SPL_MERGE));
             std::swap(cur, other);
             Hh /= 2; Ww /= 2; C *= 2;
             HIPCHK(h, tap((size_t)B * Hh * Ww * C));
@@ -599,16 +677,16 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
 }
 
 static int get_tick_graph(mnx_engine* h, int slots, int rows, float* trace, int trace_rows, hipStream_t s,
-                          hipGraphExec_t* out) {
+                          hipGraphExec_t* out, const int* forced = nullptr) {
     *out = nullptr;
     if (!h->use_graph) return MNX_OK;
-    GraphKey key{slots, rows, trace ? trace_rows : 0};
+    GraphKey key{slots, rows, trace ? trace_rows : 0, forced ? trace_rows : 0};
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { *out = it->second; return MNX_OK; }
     hipGraph_t g = nullptr;
     hipGraphExec_t exec = nullptr;
     HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s);
+    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced);
     hipError_t e2 = hipStreamEndCapture(s, &g);
     if (e != hipSuccess || e2 != hipSuccess) {
         h->err = std::string("decode tick capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
@@ -622,17 +700,17 @@ static int get_tick_graph(mnx_engine* h, int slots, int rows, float* trace, int 
 }
 
 static int run_ticks(mnx_engine* h, hipGraphExec_t exec, int slots, int rows, float* trace, int trace_rows, int n,
-                     hipStream_t s) {
+                     hipStream_t s, const int* forced = nullptr) {
     for (int i = 0; i < n; ++i) {
         if (exec) HIPCHK(h, hipGraphLaunch(exec, s));
-        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s));
+        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced));
     }
     return MNX_OK;
 }
 
-int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
-                      int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, float* token_logp, float* hidden,
-                      float* logits_trace, void* stream) {
+static int decode_greedy_impl(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
+                              int32_t stop_on_eos, const int32_t* forced_ids, int32_t* tokens, int32_t* lengths,
+                              float* token_logp, float* hidden, float* logits_trace, void* stream) {
     if (!h) return MNX_ERR_INVALID_ARG;
     if (!features || !tokens || !lengths || B < 1) { h->err = "mnx_decode_greedy: null/empty argument"; return MNX_ERR_INVALID_ARG; }
     if (B > ROW_TILE || max_len < 1 || max_len > h->cfg.max_len) {
@@ -661,13 +739,25 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
         }
         trace = h->out_trace;
     }
+    const int* forced = nullptr;
+    if (forced_ids) {    // teacher forcing: the caller's [B, max_len] ids, re-strided to the state's [slot][T] rows
+        if (!h->forced_ids) {
+            const size_t bytes = (size_t)ROW_TILE * c.max_len * 4;
+            HIPCHK(h, hipMalloc((void**)&h->forced_ids, bytes));
+            h->allocs.push_back(h->forced_ids);
+            h->bytes += bytes;
+        }
+        HIPCHK(h, hipMemcpy2DAsync(h->forced_ids, (size_t)h->db.T * 4, forced_ids, (size_t)max_len * 4, (size_t)max_len * 4, B,
+                                   hipMemcpyDeviceToDevice, s));
+        forced = h->forced_ids;
+    }
     hipGraphExec_t exec = nullptr;
-    int rc = get_tick_graph(h, ROW_TILE, ROW_TILE, trace, B, s, &exec);
+    int rc = get_tick_graph(h, ROW_TILE, ROW_TILE, trace, B, s, &exec, forced);
     if (rc != MNX_OK) return rc;
     const int poll = 8;
     for (int t = 0; t < max_len;) {
         const int n = std::min(poll, max_len - t);
-        rc = run_ticks(h, exec, ROW_TILE, ROW_TILE, trace, B, n, s);
+        rc = run_ticks(h, exec, ROW_TILE, ROW_TILE, trace, B, n, s, forced);
         if (rc != MNX_OK) return rc;
         t += n;
         HIPCHK(h, dec_enqueue_status(h->db, ROW_TILE, s));
@@ -679,6 +769,21 @@ int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int
     if (logits_trace) HIPCHK(h, hipMemcpyAsync(logits_trace, trace, (size_t)max_len * B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));
     return MNX_OK;
+}
+
+int mnx_decode_greedy(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
+                      int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, float* token_logp, float* hidden,
+                      float* logits_trace, void* stream) {
+    return decode_greedy_impl(h, features, B, chunk_id, max_len, stop_on_eos, nullptr, tokens, lengths, token_logp, hidden,
+                              logits_trace, stream);
+}
+
+int mnx_decode_forced(mnx_engine* h, const float* features, int32_t B, const int32_t* chunk_id, int32_t max_len,
+                      const int32_t* forced_ids, int32_t* argmax_ids, int32_t* lengths, float* forced_logp,
+                      float* logits_trace, void* stream) {
+    if (h && !forced_ids) { h->err = "mnx_decode_forced: forced_ids is null"; return MNX_ERR_INVALID_ARG; }
+    return decode_greedy_impl(h, features, B, chunk_id, max_len, 1, forced_ids, argmax_ids, lengths, forced_logp, nullptr,
+                              logits_trace, stream);
 }
 
 int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t beam, int32_t n_best, int32_t max_len,
@@ -836,7 +941,7 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
                                 edges + (size_t)first * kmax * kmax, nullptr, s));
     }
     HIPCHK(h, hipStreamSynchronize(s));
-    return MNX_OK;
+    return check_encoder_range(h, s);
 }
 
 int mnx_preprocess(mnx_engine* h, const uint8_t* rgb, int32_t height, int32_t width, int32_t pad,
@@ -1049,7 +1154,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     }
     HIPCHK(h, hipStreamSynchronize(s));
     if (tf) fprintf(tf, "%.3f end host_wait_ms %.3f\n", now_ms() - t_begin, host_wait_ms);
-    return MNX_OK;
+    return check_encoder_range(h, s);
 }
 
 int mnx_profile_enable(mnx_engine* h, int32_t enable) {
@@ -1105,8 +1210,22 @@ int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C
                int32_t N, int32_t K, void* stream) {
     if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, launch_gemm16(h->cfg.compute_dtype, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
+    HIPCHK(h, launch_gemm16(dt_base(h->cfg.compute_dtype), epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
                             M, N, K, (hipStream_t)stream));
+    return MNX_OK;
+}
+
+int mnx_gemm16_split(mnx_engine* h, int32_t epi, const void* A, int64_t a_lo, const void* W, int64_t w_lo, float oscale,
+                     void* C, int64_t c_lo, const float* bias, int32_t M, int32_t N, int32_t K, int32_t terms,
+                     void* stream) {
+    if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
+    if (!dt_split(h->cfg.compute_dtype)) { h->err = "mnx_gemm16_split: the engine's compute_dtype is not a split mode"; return MNX_ERR_INVALID_ARG; }
+    if (a_lo < 0 || w_lo < 0 || c_lo < 0) { h->err = "mnx_gemm16_split: negative plane offset"; return MNX_ERR_INVALID_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    SplitArgs sp;
+    sp.a_lo = (size_t)a_lo; sp.w_lo = (size_t)w_lo; sp.c_lo = (size_t)c_lo; sp.oscale = oscale; sp.terms = terms;
+    HIPCHK(h, launch_gemm16(h->cfg.compute_dtype, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr, M, N,
+                            K, (hipStream_t)stream, &sp));
     return MNX_OK;
 }
 

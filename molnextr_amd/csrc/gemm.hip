@@ -94,11 +94,72 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
     }
 }
 
+// Epilogue of the split-operand modes (kernels.h SplitArgs): C = epi(oscale * acc + bias) with the exact-erf GELU (the
+// point of these modes is fp32-class results), 16-bit outputs written as TWO planes (hi, then lo = v - hi, c_lo elements
+// behind) through the same LDS transposition; fp32 outputs go through gemm_epilogue unchanged.
 template <typename T, int EPI, int BN>
+__device__ __forceinline__ void gemm_epilogue_split(f32x4 (&acc)[BN / 32][4], char* smem, void* Cout,
+                                                    const float* __restrict__ bias, const float* resid, int M, int N,
+                                                    int m0, int n0, int wm, int wn, int fr, int fg, const SplitArgs sp) {
+    typedef typename H16<T>::v4 v4;
+    typedef typename H16<T>::v8 v8;
+    constexpr int NT = BN / 32;
+    constexpr bool OUT16 = (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16);
+    if (!OUT16) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] *= sp.oscale;
+        gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
+        return;
+    }
+    constexpr int ROWB = BN * 2 + 16;
+    constexpr int CH_ROW = BN * 2 / 16;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nl = wn * (BN / 2) + nt * 16 + fg * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n0 + nl < N) b4 = *(const f32x4*)(bias + n0 + nl);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 v = acc[nt][mt] * sp.oscale + b4;
+            if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            acc[nt][mt] = v;
+        }
+    }
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int nl = wn * (BN / 2) + nt * 16 + fg * 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int ml = wm * 64 + mt * 16 + fr;
+                v4 hi, lo;
+                split16x4<T>(acc[nt][mt], hi, lo);
+                *(v4*)(smem + ml * ROWB + nl * 2) = plane == 0 ? hi : lo;
+            }
+        }
+        __syncthreads();
+        T* Cp = (T*)Cout + (plane == 0 ? (size_t)0 : sp.c_lo);
+#pragma unroll
+        for (int i = 0; i < BM * CH_ROW / 256; ++i) {
+            const int id = tid + i * 256;
+            const int rl = id / CH_ROW, ch = id % CH_ROW;
+            const int m = m0 + rl;
+            const int n = n0 + ch * 8;
+            if (m < M && n < N) *(v8*)(Cp + (size_t)m * N + n) = *(const v8*)(smem + rl * ROWB + ch * 16);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int EPI, int BN, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                       void* Cout, const float* __restrict__ bias,
                                                       const float* resid, int M, int N, int K, int tiles_n,
-                                                      int n_tiles) {
+                                                      int n_tiles, const SplitArgs sp) {
     typedef typename H16<T>::v8 v8;
     constexpr int NT = BN / 32;          // 16-wide n-tiles per wave (waves are 2(M) x 2(N))
     constexpr int WLD = BN / 32;         // W chunks per thread per K-tile
@@ -119,16 +180,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         a_ptr[i] = A + (size_t)ra * K + ld_c * 8;
         w_ptr[i] = W + (size_t)rw * K + ld_c * 8;
     }
-    const int nk = (K + BK - 1) / BK;
+    // split modes: K-tile j of the loop is term j % 3 of K-tile j / 3: (A hi, W hi), (A hi, W lo), (A lo, W hi)
+    const int nterm = SPLIT ? sp.terms : 1;
+    const int nk = ((K + BK - 1) / BK) * nterm;
     Stage<T> st;
-    auto load_g = [&](int kt) {
+    auto load_g = [&](int j) {
+        const int kt = nterm == 3 ? j / 3 : j, term = nterm == 3 ? j - kt * 3 : 0;
         const int k0 = kt * BK;
+        const size_t ka = (size_t)k0 + (term == 2 ? sp.a_lo : 0), kw = (size_t)k0 + (term == 1 ? sp.w_lo : 0);
         const bool ok = (k0 + ld_c * 8) < K;  // K % 8 == 0: a chunk is all-in or all-out
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v8 z = {};
-            st.a[i] = ok ? *(const v8*)(a_ptr[i] + k0) : z;
-            if (i < WLD) st.w[i] = ok ? *(const v8*)(w_ptr[i] + k0) : z;
+            st.a[i] = ok ? *(const v8*)(a_ptr[i] + ka) : z;
+            if (i < WLD) st.w[i] = ok ? *(const v8*)(w_ptr[i] + kw) : z;
         }
     };
     auto store_s = [&](int buf) {
@@ -172,7 +237,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         __syncthreads();
     }
 
-    gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
+    if (SPLIT) gemm_epilogue_split<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg, sp);
+    else gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
 
 // Main-loop variant with direct global->LDS DMA (global_load_lds_dwordx4): no VGPR staging, no ds_write pass.
@@ -182,10 +248,10 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 // Double-buffered K loop (64 / 48 KiB LDS, 2-3 workgroups per CU).
-template <typename T, int EPI, int BN>
+template <typename T, int EPI, int BN, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cout,
                                                            const float* __restrict__ bias, const float* resid, int M,
-                                                           int N, int K, int tiles_n, int n_tiles) {
+                                                           int N, int K, int tiles_n, int n_tiles, const SplitArgs sp) {
     typedef typename H16<T>::v8 v8;
     constexpr int NT = BN / 32;
     constexpr int WLD = BN / 32;
@@ -211,23 +277,27 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
         const int r = (wave * WLD + i) * 8 + r_in;
         w_src[i] = W + (size_t)min(n0 + r, N - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
     }
-    auto issue = [&](int kt, int buf) {
+    // split modes: K-tile j of the loop is term j % 3 of K-tile j / 3: (A hi, W hi), (A hi, W lo), (A lo, W hi) — the
+    // re-read of the hi tiles follows their first read immediately (L2 hits)
+    const int nterm = SPLIT ? sp.terms : 1;
+    auto issue = [&](int j, int buf) {
         char* ab = smem + buf * STG;
         char* wb = ab + BM * BK * 2;
-        const int k0 = kt * BK;
+        const int kt = nterm == 3 ? j / 3 : j, term = nterm == 3 ? j - kt * 3 : 0;
+        const size_t ka = (size_t)kt * BK + (term == 2 ? sp.a_lo : 0), kw = (size_t)kt * BK + (term == 1 ? sp.w_lo : 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + k0), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + ka), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < WLD; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + k0), (lds_void_t*)(wb + (wave * WLD + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + kw), (lds_void_t*)(wb + (wave * WLD + i) * 1024), 16, 0, 0);
     };
     f32x4 acc[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nk = K / BK;
+    const int nk = (K / BK) * nterm;
     issue(0, 0);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
@@ -249,7 +319,8 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
         }
         __syncthreads();   // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer kt&1 for tile kt+2
     }
-    gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
+    if (SPLIT) gemm_epilogue_split<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg, sp);
+    else gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
 }
 
 // fp32 "parity mode" GEMM (compute_dtype FP32): C = epi(A.W^T + b) with fp32 operands on v_mfma_f32_16x16x4_f32 (exact
@@ -328,20 +399,20 @@ static hipError_t launch_f32(int epi, const void* A, const void* W, void* C, con
     return hipGetLastError();
 }
 
-template <typename T, int BN>
+template <typename T, int BN, bool SPLIT>
 static hipError_t launch_bn(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
-                            int M, int N, int K, hipStream_t s) {
+                            int M, int N, int K, hipStream_t s, const SplitArgs& sp) {
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
     const bool glds = (K % BK) == 0;
 #define MNX_GEMM_CASE(E)                                                                                                  \
     case E:                                                                                                               \
         if (glds)                                                                                                         \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias,    \
-                               resid, M, N, K, tn, tm * tn);                                                              \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<T, E, BN, SPLIT>), grid, block, 0, s, (const T*)A, (const T*)W, C,   \
+                               bias, resid, M, N, K, tn, tm * tn, sp);                                                    \
         else                                                                                                              \
-            hipLaunchKernelGGL((gemm_tn_kernel<T, E, BN>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias, resid,  \
-                               M, N, K, tn, tm * tn);                                                                     \
+            hipLaunchKernelGGL((gemm_tn_kernel<T, E, BN, SPLIT>), grid, block, 0, s, (const T*)A, (const T*)W, C, bias,  \
+                               resid, M, N, K, tn, tm * tn, sp);                                                          \
         break;
     switch (epi) {
         MNX_GEMM_CASE(EPI_BIAS_16)
@@ -354,32 +425,38 @@ static hipError_t launch_bn(int epi, const void* A, const void* W, void* C, cons
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, bool SPLIT>
 static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const float* bias, const float* resid,
-                           int M, int N, int K, hipStream_t s) {
+                           int M, int N, int K, hipStream_t s, const SplitArgs& sp) {
     // tile choice: 128x128 unless its tile count leaves the 512 resident-workgroup slots (256 CUs x 2) badly
     // quantised; then 128x64 tiles (3 workgroups per CU)
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const double waves128 = (double)t128 / 512.0;
     const bool small = t128 < 512 || (waves128 < 3.0 && (waves128 - (long)waves128) > 0.0 && (waves128 - (long)waves128) < 0.6);
-    if ((small || N <= 128) && N >= 64) return launch_bn<T, 64>(epi, A, W, C, bias, resid, M, N, K, s);   // N = 128: +10 %
-    return launch_bn<T, 128>(epi, A, W, C, bias, resid, M, N, K, s);
+    if ((small || N <= 128) && N >= 64) return launch_bn<T, 64, SPLIT>(epi, A, W, C, bias, resid, M, N, K, s, sp);   // N = 128: +10 %
+    return launch_bn<T, 128, SPLIT>(epi, A, W, C, bias, resid, M, N, K, s, sp);
 }
 
 hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
-                                 const float* resid, int M, int N, int K, hipStream_t s) {
+                                 const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
     if ((K & 7) || (N & 7) || M <= 0) return hipErrorInvalidValue;
     if (dtype == MNX_DT_F32) return launch_f32(epi, A, W, C, bias, resid, M, N, K, s);
-    return dtype == MNX_DT_F16 ? launch_t<f16_t>(epi, A, W, C, bias, resid, M, N, K, s)
-                               : launch_t<bf16_t>(epi, A, W, C, bias, resid, M, N, K, s);
+    if (dt_split(dtype)) {
+        if (!sp || (sp->terms != 1 && sp->terms != 3)) return hipErrorInvalidValue;
+        return dtype == MNX_DT_F16X3 ? launch_t<f16_t, true>(epi, A, W, C, bias, resid, M, N, K, s, *sp)
+                                     : launch_t<bf16_t, true>(epi, A, W, C, bias, resid, M, N, K, s, *sp);
+    }
+    const SplitArgs none;
+    return dtype == MNX_DT_F16 ? launch_t<f16_t, false>(epi, A, W, C, bias, resid, M, N, K, s, none)
+                               : launch_t<bf16_t, false>(epi, A, W, C, bias, resid, M, N, K, s, none);
 }
 
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
-                         const float* resid, int M, int N, int K, hipStream_t s) {
+                         const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
     // shape-only dispatch (never data- or environment-dependent): the persistent 256x256 kernel for the 16-bit-output
     // layers whose tile count fills the chip, the 128x128 kernel for everything else
-    if (bias && gemm256_supports(dtype, epi, M, N, K)) return launch_gemm256(dtype, epi, A, W, C, bias, M, N, K, s);
-    return launch_gemm16_tile128(dtype, epi, A, W, C, bias, resid, M, N, K, s);
+    if (bias && gemm256_supports(dtype, epi, M, N, K)) return launch_gemm256(dtype, epi, A, W, C, bias, M, N, K, s, sp);
+    return launch_gemm16_tile128(dtype, epi, A, W, C, bias, resid, M, N, K, s, sp);
 }
 
 }  // namespace mnx

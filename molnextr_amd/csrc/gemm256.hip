@@ -60,22 +60,29 @@ constexpr int P_STG = 2048;                        // per-wave staging patch: 16
 constexpr int P_LDS = 8 * SLOT + 8 * P_STG;        // 144 KiB
 constexpr int P_STORES = 16, P_BIAS = 4;           // VMEM operations per wave per tile besides the fills
 
-template <typename T, int EPI>
+// SPLIT (kernels.h SplitArgs, dtypes BF16X3 / F16X3): the K-tile stream of a tile is 3 nk long — K-tile j is term j % 3 of
+// K-tile j / 3: (A hi, W hi), (A hi, W lo), (A lo, W hi), so the second read of a hi slab follows its first immediately
+// (L2 hit) — and the epilogue computes epi(oscale * acc + bias) with the exact-erf GELU and stores TWO planes (hi, lo):
+// 2 x P_STORES stores per wave per tile.
+template <typename T, int EPI, bool SPLIT>
 __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W, T* __restrict__ C,
                                                        const float* __restrict__ bias, int M, int N, int K, int tiles_n,
-                                                       int n_tiles) {
+                                                       int n_tiles, const SplitArgs sp) {
     static_assert(EPI == EPI_BIAS_16 || EPI == EPI_GELU_16, "persistent form: 16-bit outputs only");
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
+    constexpr int PST = SPLIT ? 2 * P_STORES : P_STORES;          // stores per wave per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 8 ring slots of 16 KiB + 8 staging patches
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
-    const int nk = K / TK;
+    const int nterm = SPLIT ? sp.terms : 1;
+    const int nk = K / TK, nkk = nk * nterm;              // K-tiles per output tile: operand K-tiles x product terms
     const int my_first = blockIdx.x, stride = gridDim.x;
     const int my_tiles = (n_tiles - my_first + stride - 1) / stride;
-    const int total_kt = my_tiles * nk;                   // K-tiles this workgroup streams through the ring
+    const int total_kt = my_tiles * nkk;                  // K-tiles this workgroup streams through the ring
+    const long a_lo_b = SPLIT ? (long)sp.a_lo * 2 : 0, w_lo_b = SPLIT ? (long)sp.w_lo * 2 : 0;
 
     // per-thread byte offsets of its two DMA pieces inside a tile (tile origin and K offset live in scalar registers)
     const int r_in = lane >> 3, pc = lane & 7;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
         }
     }
     // the fill stream's position: K-tile `f` (slots 0..2 are issued two K-tiles ahead, slot 3 one K-tile ahead)
-    struct Pos { const char* a; const char* w; int kt, seq; };
+    struct Pos { const char* a; const char* w; int kt, seq, term; };
     auto tile_origin = [&](int seq, int& m0, int& n0) {
         const int tile = xcd_remap(my_first + seq * stride, n_tiles);
         m0 = (tile / tiles_n) * TM; n0 = (tile % tiles_n) * TN;
@@ -99,9 +106,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
     auto pos_at = [&](int seq) {
         int m0, n0; tile_origin(seq, m0, n0);
         Pos q; q.a = (const char*)(A + (size_t)m0 * K); q.w = (const char*)(W + (size_t)n0 * K); q.kt = 0; q.seq = seq;
+        q.term = 0;
         return q;
     };
     auto advance = [&](Pos& q) {
+        if (SPLIT && nterm == 3) {
+            if (q.term == 0) { q.w += w_lo_b; q.term = 1; return; }                    // (A hi, W lo)
+            if (q.term == 1) { q.w -= w_lo_b; q.a += a_lo_b; q.term = 2; return; }     // (A lo, W hi)
+            q.a -= a_lo_b; q.term = 0;
+        }
         if (++q.kt == nk) { if (q.seq + 1 < my_tiles) q = pos_at(q.seq + 1); else { q.kt = 0; ++q.seq; } }
         else { q.a += TK * 2; q.w += TK * 2; }
     };
@@ -162,11 +175,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
         for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                f32x4 v = acc[mt][nt] + b4[nt];
-                if (EPI == EPI_GELU_16) v = gelu_fast4(v);
+                f32x4 v;
+                if (SPLIT) {
+                    v = acc[mt][nt] * sp.oscale + b4[nt];
+                    if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                    acc[mt][nt] = v;                                   // kept for the lo plane
+                } else {
+                    v = acc[mt][nt] + b4[nt];
+                    if (EPI == EPI_GELU_16) v = gelu_fast4(v);
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
                 const v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
                 *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = o4;
-                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             // the wave's LDS operations execute in order: the reads below see the slab, the next slab's writes
             // follow these reads
@@ -176,10 +196,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
                 const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
                 *(v8*)(crow + (size_t)(mt * 16 + 8 * i) * N) = o8;
             }
+            if (SPLIT) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    v4 hi, lo;
+                    split16x4<T>(acc[mt][nt], hi, lo);
+                    *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = lo;
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = (lane >> 3) + 8 * i;
+                    const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                    *(v8*)(crow + sp.c_lo + (size_t)(mt * 16 + 8 * i) * N) = o8;
+                }
+            }
         }
     };
     for (int gk = 0; gk < total_kt; ++gk) {
-        const bool last_kt = (kt == nk - 1);
+        const bool last_kt = (kt == nkk - 1);
         const char* buf = smem + (gk & 1) * 4 * SLOT;
         const bool tail = gk + 2 >= total_kt;     // the ring is running dry: drain instead of counting
         const bool first_kt = (kt == 0 && seq > 0), second_kt = (kt == 1 && seq > 0);
@@ -202,7 +237,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
         // stores of the epilogue], this phase's fill [+ 4 bias loads]; after a tile's first K-tile the bias loads of
         // that K-tile are younger than the fill issued just before them.
         if (tail) wait_vm<0>();
-        else if (first_kt) wait_vm<8 + P_STORES + P_BIAS>();
+        else if (first_kt) wait_vm<8 + PST + P_BIAS>();
         else if (second_kt) wait_vm<8 + P_BIAS>();
         else wait_vm<8>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -230,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
         // Am0, Bn0, Bn1 of the next K-tile, issued in phase B of the previous one. Younger: [16 stores], the fill of
         // phase A(gk) [+ 4 bias loads], this phase's three fills.
         if (tail) wait_vm<0>();
-        else if (first_kt) wait_vm<8 + P_STORES + P_BIAS>();
+        else if (first_kt) wait_vm<8 + PST + P_BIAS>();
         else wait_vm<8>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -267,7 +302,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 }  // namespace
 
 bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
-    if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16) return false;
+    if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16 && !dt_split(dtype)) return false;
     if (epi != EPI_BIAS_16 && epi != EPI_GELU_16) return false;
     if (M % TM || N % TN || K % TK || K < 2 * TK) return false;
     // one workgroup per CU walks tiles in rounds of 256: below one round, or when the last round is mostly empty, the
@@ -276,25 +311,44 @@ bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
     return tiles >= 256 && tiles * 10 >= rounds * 256 * 7;
 }
 
+// The 144 KiB dynamic-LDS opt-in is a per-device, per-function attribute: set once per (device, instantiation), so that
+// several handles on different GPUs of one process all get it (include/molnextr_hip.h allows that).
+template <typename K>
+static hipError_t lds_opt_in(K kernel) {
+    static unsigned long long done = 0;          // bit d: device d has the attribute (<= 64 devices per process)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
+    return e;
+}
+
 hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
-                          int K, hipStream_t s) {
+                          int K, hipStream_t s, const SplitArgs* sp) {
     if (!bias || M % TM || N % TN || K % TK || K < 2 * TK) return hipErrorInvalidValue;
+    const bool split = dt_split(dtype);
+    if (split && (!sp || (sp->terms != 1 && sp->terms != 3))) return hipErrorInvalidValue;
+    const SplitArgs spv = split ? *sp : SplitArgs();
     const int tm = M / TM, tn = N / TN;
     const int grid = tm * tn < 256 ? tm * tn : 256;
-#define MNX_G256_CASE(TT, E)                                                                                              \
+#define MNX_G256_CASE(TT, E, SP)                                                                                          \
     case E: {                                                                                                             \
-        static const hipError_t attr = hipFuncSetAttribute((const void*)gemm256_kernel<TT, E>,                            \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);            \
+        const hipError_t attr = lds_opt_in(gemm256_kernel<TT, E, SP>);                                                    \
         if (attr != hipSuccess) return attr;                                                                              \
-        hipLaunchKernelGGL((gemm256_kernel<TT, E>), dim3(grid), dim3(512), P_LDS, s, (const TT*)A, (const TT*)W, (TT*)C,  \
-                           bias, M, N, K, tn, tm * tn);                                                                   \
+        hipLaunchKernelGGL((gemm256_kernel<TT, E, SP>), dim3(grid), dim3(512), P_LDS, s, (const TT*)A, (const TT*)W,      \
+                           (TT*)C, bias, M, N, K, tn, tm * tn, spv);                                                      \
         break;                                                                                                            \
     }
-    if (dtype == MNX_DT_F16) {
-        switch (epi) { MNX_G256_CASE(f16_t, EPI_BIAS_16) MNX_G256_CASE(f16_t, EPI_GELU_16) default: return hipErrorInvalidValue; }
-    } else {
-        switch (epi) { MNX_G256_CASE(bf16_t, EPI_BIAS_16) MNX_G256_CASE(bf16_t, EPI_GELU_16) default: return hipErrorInvalidValue; }
-    }
+#define MNX_G256_TYPE(TT, SP)                                                                                             \
+    switch (epi) { MNX_G256_CASE(TT, EPI_BIAS_16, SP) MNX_G256_CASE(TT, EPI_GELU_16, SP) default: return hipErrorInvalidValue; }
+    if (dtype == MNX_DT_F16) { MNX_G256_TYPE(f16_t, false) }
+    else if (dtype == MNX_DT_BF16) { MNX_G256_TYPE(bf16_t, false) }
+    else if (dtype == MNX_DT_F16X3) { MNX_G256_TYPE(f16_t, true) }
+    else if (dtype == MNX_DT_BF16X3) { MNX_G256_TYPE(bf16_t, true) }
+    else return hipErrorInvalidValue;
+#undef MNX_G256_TYPE
 #undef MNX_G256_CASE
     return hipGetLastError();
 }

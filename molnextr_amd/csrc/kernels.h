@@ -5,37 +5,62 @@
 
 namespace mnx {
 
-enum { MNX_DT_BF16 = 0, MNX_DT_F16 = 1, MNX_DT_F32 = 2 };   // F32: parity mode, every encoder operand in fp32
-inline size_t dt_size(int dtype) { return dtype == MNX_DT_F32 ? 4 : 2; }
+// F32: parity mode, every encoder operand in fp32 on the exact-fp32 MFMA (1/16 rate).
+// BF16X3 / F16X3: split-operand modes. Every GEMM / attention operand v is carried as two 16-bit planes
+// hi = T(v), lo = T(v - hi), and every product a.b is evaluated as ah.bh + ah.bl + al.bh on the 16-bit MFMA with fp32
+// accumulation (the dropped al.bl term is 2^-22 relative for fp16, 2^-16 for bf16): fp32-class results at a third of the
+// 16-bit MFMA rate instead of a sixteenth.
+enum { MNX_DT_BF16 = 0, MNX_DT_F16 = 1, MNX_DT_F32 = 2, MNX_DT_BF16X3 = 3, MNX_DT_F16X3 = 4 };
+inline bool dt_split(int dtype) { return dtype == MNX_DT_BF16X3 || dtype == MNX_DT_F16X3; }
+inline int dt_base(int dtype) { return dtype == MNX_DT_BF16X3 ? MNX_DT_BF16 : dtype == MNX_DT_F16X3 ? MNX_DT_F16 : dtype; }
+// bytes per operand element in HBM (split modes: two 2-byte planes)
+inline size_t dt_size(int dtype) { return (dtype == MNX_DT_F32 || dt_split(dtype)) ? 4 : 2; }
 enum { EPI_BIAS_16 = 0, EPI_GELU_16 = 1, EPI_RESID_F32 = 2, EPI_BIAS_F32 = 3 };
+
+// Split-operand GEMM arguments (dtype BF16X3 / F16X3). *_lo = ELEMENT offset of an operand's lo plane from its hi plane
+// (the pointer passed as A / W / C); C = epi(oscale * acc + bias): the weights of the fp16 split are stored scaled by a
+// power of two per matrix (their lo plane would otherwise be subnormal), oscale undoes it exactly.
+// terms: 3 = hi.hi + hi.lo + lo.hi; 1 = hi.hi only (error-budget aid: the layer runs as the plain 16-bit mode would,
+// but still writes both output planes).
+struct SplitArgs {
+    size_t a_lo = 0, w_lo = 0, c_lo = 0;
+    float oscale = 1.f;
+    int terms = 3;
+};
 
 // ---- gemm.hip -------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] . W[N,K]^T + bias). A, W 16-bit (dtype). resid/C fp32 for EPI_RESID_F32 (may alias).
+// dtype BF16X3 / F16X3: A, W (and C for the 16-bit-output epilogues) are hi planes, `sp` is required.
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
-                         const float* resid, int M, int N, int K, hipStream_t s);
+                         const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp = nullptr);
 // the 128x128-tile kernel of gemm.hip without the dispatch to gemm256.hip (tools/gemm_lab compares the two)
 hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
-                                 const float* resid, int M, int N, int K, hipStream_t s);
+                                 const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp = nullptr);
 
 // ---- gemm256.hip: persistent 256x256-tile form for the 16-bit-output epilogues (bias, bias + GELU); bias required ----
 bool gemm256_supports(int dtype, int epi, int M, int N, int K);   // shape / epilogue fit AND the tile count fills 256 CUs
 hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
-                          int K, hipStream_t s);
+                          int K, hipStream_t s, const SplitArgs* sp = nullptr);
 
 // ---- encoder.hip ----------------------------------------------------------------------------
 // images [B,3,S,S] fp32 NCHW -> x [B,(S/4)^2,C] fp32 (conv 4x4/4 + bias + LayerNorm, eps 1e-5)
 hipError_t launch_patch_embed(const float* img, const float* w_t /*[48][C]*/, const float* bias, const float* gamma,
                               const float* beta, float* x, int B, int S, int C, hipStream_t s);
-// y16[M,C] = LayerNorm(x[M,C]) (eps) as 16-bit; optionally also fp32 copy y32
+// y16[M,C] = LayerNorm(x[M,C]) (eps) as 16-bit; optionally also fp32 copy y32. Split dtypes: y16 = hi plane, the lo plane
+// is written y_lo ELEMENTS behind it. nonfinite_flag (device int, may be null): set to 1 when a row's result is not finite.
 hipError_t launch_layernorm16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, float* y32,
-                              int M, int C, float eps, hipStream_t s);
+                              int M, int C, float eps, hipStream_t s, size_t y_lo = 0, int* nonfinite_flag = nullptr);
 // patch-merging gather + LayerNorm(4C): x [B,H,W,C] fp32 -> y16 [B,(H/2)(W/2),4C]
 hipError_t launch_merge_ln16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, int B, int H,
-                             int W, int C, float eps, hipStream_t s);
-// window attention: qkv16 [B*H*W, 3C] -> out16 [B*H*W, C] (original token order); table [529, heads] fp32
+                             int W, int C, float eps, hipStream_t s, size_t y_lo = 0);
+// window attention: qkv16 [B*H*W, 3C] -> out16 [B*H*W, C] (original token order); table [529, heads] fp32.
+// Split dtypes: qkv_lo / out_lo = element offsets of the lo planes; terms as SplitArgs::terms.
 hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,
-                              int C, int heads, int shift, hipStream_t s);
-hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStream_t s);
+                              int C, int heads, int shift, hipStream_t s, size_t qkv_lo = 0, size_t out_lo = 0,
+                              int terms = 3);
+// y16 = T(x) (n elements). Split dtypes: hi plane = T(scale * x), lo plane (y_lo elements behind) = T(scale * x - hi).
+hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStream_t s, size_t y_lo = 0,
+                         float scale = 1.f);
 
 // ---- preprocess.hip -------------------------------------------------------------------------
 // HWC uint8 RGB page -> [3,S,S] fp32 (CropWhite(pad) + bilinear resize + gray + ImageNet normalise); bbox: 4 ints scratch

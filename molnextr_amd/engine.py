@@ -18,11 +18,18 @@ from . import weights as W
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmolnextr_hip.so")
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
            "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess",
-           "mnx_probe_decode_attn", "mnx_predict_beam")
+           "mnx_probe_decode_attn", "mnx_predict_beam", "mnx_set_split_terms", "mnx_encoder_status",
+           "mnx_gemm16_split", "mnx_decode_forced")
+
+# Encoder operand modes (include/molnextr_hip.h MNX_DTYPE_*). "fp16x3" — split fp16 operands, three MFMA terms per
+# product, fp32-class results — is the default: it is the fastest mode whose tokens / atoms / bonds equal the reference's.
+DTYPES = {"bf16": 0, "fp16": 1, "fp32": 2, "bf16x3": 3, "fp16x3": 4}
+DEFAULT_DTYPE = "fp16x3"
+SPLIT_CLASSES = {"qkv": 1, "attn": 2, "proj": 4, "fc1": 8, "fc2": 16, "merge": 32}
 
 
 class MnxConfig(C.Structure):
@@ -70,12 +77,20 @@ def load_library():
     lib.mnx_encode.argtypes = [vp, vp, i32, vp, vp]
     lib.mnx_set_encoder_tap.restype = C.c_int
     lib.mnx_set_encoder_tap.argtypes = [vp, i32, vp]
+    lib.mnx_set_split_terms.restype = C.c_int
+    lib.mnx_set_split_terms.argtypes = [vp, i32]
+    lib.mnx_encoder_status.restype = C.c_int
+    lib.mnx_encoder_status.argtypes = [vp, C.POINTER(i32), vp]
     lib.mnx_decode_greedy.restype = C.c_int
     lib.mnx_decode_greedy.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.mnx_decode_forced.restype = C.c_int
+    lib.mnx_decode_forced.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.mnx_edges.restype = C.c_int
     lib.mnx_edges.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.mnx_gemm16.restype = C.c_int
     lib.mnx_gemm16.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mnx_gemm16_split.restype = C.c_int
+    lib.mnx_gemm16_split.argtypes = [vp, i32, vp, C.c_int64, vp, C.c_int64, C.c_float, vp, C.c_int64, vp, i32, i32, i32, i32, vp]
     lib.mnx_profile_enable.restype = C.c_int
     lib.mnx_profile_enable.argtypes = [vp, i32]
     lib.mnx_profile_read.restype = C.c_int
@@ -115,7 +130,7 @@ class Engine:
 
     def __init__(self, encoder_state: Dict[str, torch.Tensor], decoder_state: Dict[str, torch.Tensor],
                  device: int = 0, max_batch: int = 32, enc: W.EncoderDims = W.SWIN_B, dec: W.DecoderDims = W.DEC,
-                 dtype: str = "bf16", max_len: int = 480, max_atoms: int = 160, dec_slots: int = 2048):
+                 dtype: str = DEFAULT_DTYPE, max_len: int = 480, max_atoms: int = 160, dec_slots: int = 2048):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise MnxError("no HIP device visible: molnextr_amd needs an MI355X (gfx950); there is no CPU fallback")
@@ -137,7 +152,9 @@ class Engine:
         cfg.dec_layers, cfg.dec_dim, cfg.dec_heads, cfg.dec_ff = dec.layers, dec.d_model, dec.heads, dec.d_ff
         cfg.vocab, cfg.sym_offset, cfg.coord_bins, cfg.pe_len = dec.vocab, dec.vocab - 128, 64, dec.pe_len
         cfg.max_len, cfg.max_batch, cfg.max_atoms = max_len, max_batch, max_atoms
-        cfg.compute_dtype = {"bf16": 0, "fp16": 1, "fp32": 2}[dtype]
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(DTYPES)}, got {dtype!r}")
+        cfg.compute_dtype = DTYPES[dtype]
         cfg.dec_slots = dec_slots
         self.dtype = dtype
         keep, descs = [], []
@@ -206,6 +223,19 @@ class Engine:
     def set_tap(self, item: int, dst: Optional[torch.Tensor]):
         self._check(self.lib.mnx_set_encoder_tap(self.h, item, _ptr(dst)), "mnx_set_encoder_tap")
 
+    def set_split_terms(self, three_term_classes=None):
+        """Split modes only (test aid): the op classes (names of SPLIT_CLASSES) evaluated with all three product terms;
+        the others run hi.hi alone, as the plain 16-bit mode would. None = all classes (the default)."""
+        mask = 63 if three_term_classes is None else sum(SPLIT_CLASSES[c] for c in three_term_classes)
+        self._check(self.lib.mnx_set_split_terms(self.h, mask), "mnx_set_split_terms")
+
+    def encoder_nonfinite(self) -> bool:
+        """Synchronises and reports (then clears) whether an encode since the last call produced non-finite features
+        (fp16 operand range exceeded)."""
+        flag = C.c_int32(0)
+        self._check(self.lib.mnx_encoder_status(self.h, C.byref(flag), _stream()), "mnx_encoder_status")
+        return bool(flag.value)
+
     # -- TransformerDecoderAR.decode (greedy) ----------------------------------------------------
     def decode_greedy(self, features: torch.Tensor, chunk_id: Optional[torch.Tensor] = None,
                       max_len: Optional[int] = None, stop_on_eos: bool = True, want_hidden: bool = True,
@@ -226,6 +256,26 @@ class Engine:
                                         _stream())
         self._check(rc, "mnx_decode_greedy")
         return {"tokens": tokens, "lengths": lengths, "token_logp": logp, "hidden": hidden, "logits": trace}
+
+    def decode_forced(self, features: torch.Tensor, forced_ids: torch.Tensor, max_len: Optional[int] = None,
+                      trace_logits: bool = False) -> dict:
+        """Teacher-forced greedy decode (test aid, mnx_decode_forced): rows advance with forced_ids [B,max_len] (each
+        ending with EOS or filling max_len). Returns the engine's own argmax at every step given that history
+        ('argmax'), the masked log-prob of the forced id ('forced_logp'), 'lengths' and optionally 'logits'."""
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        B = features.shape[0]
+        max_len = self.max_len if max_len is None else max_len
+        dev = features.device
+        forced = forced_ids.to(device=dev, dtype=torch.int32).contiguous()
+        assert tuple(forced.shape) == (B, max_len), forced.shape
+        argmax = torch.zeros(B, max_len, dtype=torch.int32, device=dev)
+        lengths = torch.empty(B, dtype=torch.int32, device=dev)
+        logp = torch.zeros(B, max_len, dtype=torch.float32, device=dev)
+        trace = torch.empty(max_len, B, self.dec.vocab, dtype=torch.float32, device=dev) if trace_logits else None
+        rc = self.lib.mnx_decode_forced(self.h, _ptr(features), B, None, max_len, _ptr(forced), _ptr(argmax), _ptr(lengths),
+                                        _ptr(logp), _ptr(trace), _stream())
+        self._check(rc, "mnx_decode_forced")
+        return {"argmax": argmax, "lengths": lengths, "forced_logp": logp, "logits": trace}
 
     # -- CropWhite + Resize + ToGray + Normalize on device ---------------------------------------------
     def preprocess(self, images, pad: int = 50, pad_to_square: bool = False, return_crops: bool = False):
@@ -333,7 +383,9 @@ class Engine:
         """True / n: bracket the GEMMs of every n-th encode call with HIP events (at most 16 calls); False: off."""
         self._check(self.lib.mnx_profile_enable(self.h, int(enable)), "mnx_profile_enable")
 
-    PROFILE_KINDS = {"gemm": 0, "layernorm": 1, "window_attn": 2, "patch_embed": 3}
+    # "gemm" = encoder GEMMs of the stages with C < 512 + the patch-merging reductions, "gemm_s34" = the block Linears
+    # with C >= 512 (Swin-B stages 3 and 4: the MFMA-bound shapes); the GEMM family is the sum of the two
+    PROFILE_KINDS = {"gemm": 0, "layernorm": 1, "window_attn": 2, "patch_embed": 3, "gemm_s34": 4}
 
     def profile_read(self, kind: str = "gemm", reset: bool = True):
         """(ms, work, launches) accumulated by HIP events for one kernel class since the last reset; work = FLOP for
@@ -356,6 +408,17 @@ class Engine:
         self._check(self.lib.mnx_probe_decode_attn(self.h, rows, t, iters, C.byref(a), C.byref(b), _stream()),
                     "mnx_probe_decode_attn")
         return a.value, b.value
+
+    def gemm16_split(self, epi: int, A2: torch.Tensor, W2: torch.Tensor, Cout: torch.Tensor,
+                     bias: Optional[torch.Tensor], oscale: float = 1.0, terms: int = 3):
+        """Split-mode GEMM on caller buffers: A2 [2,M,K] and W2 [2,N,K] hold the hi / lo planes (16-bit); Cout is
+        [2,M,N] 16-bit (epi 0, 1) or [M,N] fp32 (epi 2: bias + residual in place, 3: bias)."""
+        _, M, K = A2.shape
+        N = W2.shape[1]
+        c_lo = M * N if Cout.dim() == 3 else 0
+        self._check(self.lib.mnx_gemm16_split(self.h, epi, _ptr(A2), M * K, _ptr(W2), N * K, float(oscale), _ptr(Cout), c_lo,
+                                              _ptr(bias), M, N, K, terms, _stream()), "mnx_gemm16_split")
+        return Cout
 
     def gemm16(self, epi: int, A: torch.Tensor, Wt: torch.Tensor, Cout: torch.Tensor, bias: Optional[torch.Tensor]):
         M, K = A.shape

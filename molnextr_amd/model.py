@@ -128,9 +128,11 @@ class molnextr:
     the literal 'synthetic' opts into the deterministic hash-generated checkpoint (tests / bench only: its predictions
     are meaningless as chemistry). There is no default: like the reference, the model cannot run without weights.
     device: torch.device('cuda', i) — an MI355X is required.
-    dtype: 'bf16' (throughput mode), 'fp16', or 'fp32' (parity mode: tokens / atoms / bonds equal the reference's)."""
+    dtype: encoder operand mode. 'fp16x3' (default; split fp16 operands, three MFMA terms per product: tokens / atoms /
+    bonds equal the reference's at ~3/4 of the bf16 mode's throughput), 'bf16x3' (the same with the fp32 exponent range),
+    'fp32' (exact-fp32 MFMA, slowest), 'bf16' / 'fp16' (fastest; argmax decisions near a tie can differ)."""
 
-    def __init__(self, model_path, device=None, max_batch: int = 32, dtype: str = "bf16",
+    def __init__(self, model_path, device=None, max_batch: int = 32, dtype: str = "fp16x3",
                  device_preprocess: bool = True):
         if model_path is None:
             raise ValueError("molnextr(model_path): a checkpoint path is required (pass 'synthetic' explicitly for the "

@@ -1,6 +1,9 @@
 // tools/gemm_lab/lab.hip — standalone A/B bench of the encoder GEMM kernels on the Swin-B shapes (no Python, no engine).
 //
-//   make -C tools/gemm_lab && tools/gemm_lab/lab [images_per_group=64] [iters=20] [only-names,comma-separated]
+//   make -C tools/gemm_lab && tools/gemm_lab/lab [images_per_group=64] [iters=20] [only-names,comma-separated|-] [bf16|fp16x3]
+//
+// Mode fp16x3 times the split-operand form of the same kernels (hi + lo planes, three MFMA terms per product; TFLOP/s are
+// ALGORITHMIC, 2*M*N*K): timing only — its arithmetic is checked element by element in tests/test_gpu_parity.py.
 //
 // For every (stage, layer) GEMM shape of an encoder group it checks sampled output rows of both kernels against a naive
 // fp32 reference (same 16-bit inputs) and prints microseconds and TFLOP/s of
@@ -34,6 +37,13 @@ __global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed, float scale) {
         p[i] = (bf16_t)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
     }
 }
+__global__ void fill_f16(f16_t* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (f16_t)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
+    }
+}
 __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         unsigned h = (unsigned)(i * 2654435761u) ^ seed;
@@ -60,7 +70,9 @@ struct Shape { const char* name; int epi, M, N, K; };
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64;
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
-    const char* only = argc > 3 ? argv[3] : nullptr;
+    const char* only = (argc > 3 && strcmp(argv[3], "-")) ? argv[3] : nullptr;
+    const bool split = argc > 4 && !strcmp(argv[4], "fp16x3");
+    const int dt = split ? mnx::MNX_DT_F16X3 : mnx::MNX_DT_BF16;
     std::vector<Shape> shapes;
     const int L[4] = {9216, 2304, 576, 144}, C[4] = {128, 256, 512, 1024};
     static char names[64][32];
@@ -78,7 +90,7 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("images per group %d, %d launches per timing\n", B, iters);
+    printf("images per group %d, %d launches per timing, operands %s\n", B, iters, split ? "fp16x3 (split, 3 MFMA terms; algorithmic TFLOP/s)" : "bf16");
     printf("%-9s epi %8s %6s %6s | %10s %8s | %10s %8s %-6s| max |err| vs fp32 reference (base, disp)\n", "shape", "M", "N",
            "K", "base us", "TF", "disp us", "TF", "kernel");
     for (const Shape& sh : shapes) {
@@ -88,11 +100,19 @@ int main(int argc, char** argv) {
         bf16_t *A, *W;
         float *bias, *resid0;
         void* Cc;
-        CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&W, nW * 2)); CK(hipMalloc(&bias, sh.N * 4));
-        CK(hipMalloc(&Cc, nC * (out16 ? 2 : 4)));
+        const int planes = split ? 2 : 1;
+        CK(hipMalloc(&A, nA * 2 * planes)); CK(hipMalloc(&W, nW * 2 * planes)); CK(hipMalloc(&bias, sh.N * 4));
+        CK(hipMalloc(&Cc, nC * (out16 ? 2 * planes : 4)));
         CK(hipMalloc(&resid0, sh.epi == 2 ? nC * 4 : 16));
-        fill_bf16<<<2048, 256, 0, st>>>(A, nA, 1u, 1.0f);
-        fill_bf16<<<2048, 256, 0, st>>>(W, nW, 2u, 1.0f / sqrtf((float)sh.K));
+        if (split) {    // hi planes of unit size, lo planes 2^-11 of that (what a rounding residual looks like)
+            fill_f16<<<2048, 256, 0, st>>>((f16_t*)A, nA, 1u, 1.0f);
+            fill_f16<<<2048, 256, 0, st>>>((f16_t*)A + nA, nA, 5u, 1.0f / 2048.f);
+            fill_f16<<<2048, 256, 0, st>>>((f16_t*)W, nW, 2u, 1.0f / sqrtf((float)sh.K));
+            fill_f16<<<2048, 256, 0, st>>>((f16_t*)W + nW, nW, 6u, 1.0f / sqrtf((float)sh.K) / 2048.f);
+        } else {
+            fill_bf16<<<2048, 256, 0, st>>>(A, nA, 1u, 1.0f);
+            fill_bf16<<<2048, 256, 0, st>>>(W, nW, 2u, 1.0f / sqrtf((float)sh.K));
+        }
         fill_f32<<<64, 256, 0, st>>>(bias, sh.N, 3u, 0.5f);
         if (sh.epi == 2) fill_f32<<<2048, 256, 0, st>>>(resid0, nC, 4u, 1.0f);
         const int S = 24;
@@ -106,18 +126,20 @@ int main(int argc, char** argv) {
         std::vector<float> href((size_t)S * sh.N);
         CK(hipMemcpyAsync(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
-        const bool uses256 = mnx::gemm256_supports(mnx::MNX_DT_BF16, sh.epi, sh.M, sh.N, sh.K);
+        const bool uses256 = mnx::gemm256_supports(dt, sh.epi, sh.M, sh.N, sh.K);
+        mnx::SplitArgs sp;
+        sp.a_lo = nA; sp.w_lo = nW; sp.c_lo = out16 ? nC : 0; sp.oscale = 1.0f; sp.terms = 3;
         auto launch = [&](int v) {
             const float* resid = sh.epi == 2 ? (const float*)Cc : nullptr;      // in-place residual, as the encoder runs it
-            return v ? mnx::launch_gemm16(mnx::MNX_DT_BF16, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st)
-                     : mnx::launch_gemm16_tile128(mnx::MNX_DT_BF16, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st);
+            return v ? mnx::launch_gemm16(dt, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st, split ? &sp : nullptr)
+                     : mnx::launch_gemm16_tile128(dt, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st, split ? &sp : nullptr);
         };
         double us[2] = {0, 0}, err[2] = {0, 0};
         for (int v = 0; v < 2; ++v) {
             if (sh.epi == 2) CK(hipMemcpyAsync(Cc, resid0, nC * 4, hipMemcpyDeviceToDevice, st));
             CK(launch(v));
             std::vector<char> hrow((size_t)sh.N * 4);
-            for (int i = 0; i < S; ++i) {
+            for (int i = 0; i < S && !split; ++i) {
                 CK(hipMemcpyAsync(hrow.data(), (char*)Cc + (size_t)rows[i] * sh.N * (out16 ? 2 : 4), (size_t)sh.N * (out16 ? 2 : 4),
                                   hipMemcpyDeviceToHost, st));
                 CK(hipStreamSynchronize(st));
