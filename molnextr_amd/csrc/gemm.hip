@@ -454,8 +454,10 @@ hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* 
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                          const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
     // shape-only dispatch (never data- or environment-dependent): the persistent 256x256 kernel for the 16-bit-output
-    // layers whose tile count fills the chip, the 128x128 kernel for everything else
+    // layers whose tile count fills the chip, the persistent 256x128 kernel for the fp32-output layers likewise, the
+    // 128x128 kernel for everything else
     if (bias && gemm256_supports(dtype, epi, M, N, K)) return launch_gemm256(dtype, epi, A, W, C, bias, M, N, K, s, sp);
+    if (gemm_res_supports(dtype, epi, M, N, K)) return launch_gemm_res(dtype, epi, A, W, (float*)C, bias, resid, M, N, K, s, sp);
     return launch_gemm16_tile128(dtype, epi, A, W, C, bias, resid, M, N, K, s, sp);
 }
 

@@ -42,6 +42,11 @@ bool gemm256_supports(int dtype, int epi, int M, int N, int K);   // shape / epi
 hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
                           int K, hipStream_t s, const SplitArgs* sp = nullptr);
 
+// ---- gemm_res.hip: persistent 256x128-tile form for the fp32-output epilogues (bias + fp32 residual, bias -> fp32) ----
+bool gemm_res_supports(int dtype, int epi, int M, int N, int K);  // shape / epilogue fit AND the tile count fills 256 CUs
+hipError_t launch_gemm_res(int dtype, int epi, const void* A, const void* W, float* C, const float* bias,
+                           const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp = nullptr);
+
 // ---- encoder.hip ----------------------------------------------------------------------------
 // images [B,3,S,S] fp32 NCHW -> x [B,(S/4)^2,C] fp32 (conv 4x4/4 + bias + LayerNorm, eps 1e-5)
 hipError_t launch_patch_embed(const float* img, const float* w_t /*[48][C]*/, const float* bias, const float* gamma,

@@ -146,6 +146,47 @@ def test_gemm_persistent_256_tile_kernel(dev, dtype, M, N, K):
     e.close()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp16x3"])
+@pytest.mark.parametrize("M,N,K", [(65536, 128, 128), (65536, 128, 512), (16384, 512, 2048), (73728, 512, 512),
+                                   (32768, 256, 256), (18432, 1024, 1024)])
+def test_gemm_persistent_residual_kernel(dev, dtype, M, N, K):
+    """Shapes that launch_gemm16 routes to gemm_res.hip (fp32-output epilogues, M % 256 == 0, N % 128 == 0, >= 256 tiles):
+    the two-K-tile case (K = 128: the residual prefetch is issued in a tile's FIRST K-tile), exactly one round (256 tiles),
+    ragged rounds (4.5, 2.25), long K; bias + in-place fp32 residual, and bias -> fp32 without residual and without bias;
+    plain 16-bit and split operands; every output element is compared; the same launch twice is bit-identical."""
+    e = _tiny_engine(dtype)
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    if dtype == "fp16x3":
+        ws = 2.0 ** 12
+        A2, W2 = _split_planes(A, torch.float16), _split_planes(Wt, torch.float16, ws)
+        ref = A.double() @ Wt.double().t()
+        run = lambda epi, out, b: e.gemm16_split(epi, A2, W2, out, b, oscale=1.0 / ws)   # noqa: E731
+        tol = 3e-6 * 8
+    else:
+        td = torch.bfloat16 if dtype == "bf16" else torch.float16
+        A16, W16 = A.to(td), Wt.to(td)
+        ref = A16.double() @ W16.double().t()
+        run = lambda epi, out, b: e.gemm16(epi, A16, W16, out, b)                        # noqa: E731
+        tol = 2e-4
+    r2 = res.clone()
+    run(2, r2, bias)
+    assert (r2.double() - (ref + bias.double() + res.double())).abs().max().item() < tol
+    again = res.clone()
+    run(2, again, bias)
+    assert torch.equal(again, r2)
+    out = torch.full((M, N), 7.0, device=dev)
+    run(3, out, bias)
+    assert (out.double() - (ref + bias.double())).abs().max().item() < tol
+    out.fill_(7.0)
+    run(3, out, None)                                    # the patch-merging reduction has no bias
+    assert (out.double() - ref).abs().max().item() < tol
+    e.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [("bf16", 4e-2), ("fp16", 6e-3), ("bf16x3", 2e-4), ("fp16x3", 2e-5), ("fp32", 2e-5)])
 def test_swin_tiny_every_block_vs_reference_golden(golden_dir, dev, dtype, tol):
     gold = np.load(os.path.join(golden_dir, "swin_tiny.npz"))

@@ -8,7 +8,8 @@
 // For every (stage, layer) GEMM shape of an encoder group it checks sampled output rows of both kernels against a naive
 // fp32 reference (same 16-bit inputs) and prints microseconds and TFLOP/s of
 //   base = the 128x128 kernel of gemm.hip          (mnx::launch_gemm16_tile128)
-//   disp = what the product dispatches              (mnx::launch_gemm16: gemm256.hip where gemm256_supports())
+//   disp = what the product dispatches              (mnx::launch_gemm16: gemm256.hip where gemm256_supports(), gemm_res.hip
+//                                                    where gemm_res_supports())
 // The table under profiles/ (r02_gemm_shapes.md) is this program's output.
 #include <hip/hip_runtime.h>
 
@@ -163,7 +164,8 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * sh.M * sh.N * sh.K;
         const double tol = out16 ? 2e-2 : 1e-3;
         printf("%-9s %3d %8d %6d %6d | %10.1f %8.1f | %10.1f %8.1f %-6s| %.2e %.2e%s\n", sh.name, sh.epi, sh.M, sh.N, sh.K, us[0],
-               fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, uses256 ? "g256" : "base", err[0], err[1],
+               fl / us[0] / 1e6, us[1], fl / us[1] / 1e6,
+               uses256 ? "g256" : (mnx::gemm_res_supports(dt, sh.epi, sh.M, sh.N, sh.K) ? "gres" : "base"), err[0], err[1],
                (err[0] > tol || err[1] > tol) ? "  FAIL" : "");
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(Cc)); CK(hipFree(resid0)); CK(hipFree(drows)); CK(hipFree(ref));
     }
