@@ -242,7 +242,8 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
 
 /* Kernel-level timing aid for bench.py: runs the 16-bit MFMA GEMM of the encoder on caller buffers.
  * C[M,N] = A[M,K] . W[N,K]^T + bias, A/W 16-bit device, epi: 0 bias->16-bit, 1 bias+GELU->16-bit,
- * 2 bias+residual(fp32, in place in C), 3 bias->fp32. */
+ * 2 bias+residual(fp32, in place in C), 3 bias->fp32. epi | 0x100 (epi 2, 3; test aid) runs the persistent fp32-output
+ * kernel (gemm_res.hip) whatever the shape dispatch would choose. */
 int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C, const float* bias, int32_t M,
                int32_t N, int32_t K, void* stream);
 

@@ -47,16 +47,20 @@ template <> struct H16<float> {
 
 // Split-operand modes (kernels.h MNX_DT_BF16X3 / MNX_DT_F16X3): v = hi + lo up to 2^-22 |v| (fp16; the lo plane may be
 // subnormal, the MFMA does not flush 16-bit inputs) or 2^-17 |v| (bf16).
+// hi and lo MUST come from one evaluation of v: a caller that derives hi in one place and lo in another lets the compiler
+// evaluate v twice (contraction of v's producing multiply into the subtraction changes its last bit), and a v that sits on
+// a rounding tie then gets the hi of one neighbour with the lo of the other — an error of a whole 16-bit ulp (seen on
+// 3 of 384000 GELU outputs in round 3). __fsub_rn keeps the subtraction from being fused with whatever produced v.
 template <typename T>
 __device__ __forceinline__ void split16(float v, T& hi, T& lo) {
     hi = (T)v;
-    lo = (T)(v - (float)hi);
+    lo = (T)__fsub_rn(v, (float)hi);
 }
 template <typename T>
 __device__ __forceinline__ void split16x4(f32x4 v, typename H16<T>::v4& hi, typename H16<T>::v4& lo) {
     hi = (typename H16<T>::v4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-    lo = (typename H16<T>::v4){(T)(v[0] - (float)hi[0]), (T)(v[1] - (float)hi[1]), (T)(v[2] - (float)hi[2]),
-                               (T)(v[3] - (float)hi[3])};
+    lo = (typename H16<T>::v4){(T)__fsub_rn(v[0], (float)hi[0]), (T)__fsub_rn(v[1], (float)hi[1]),
+                               (T)__fsub_rn(v[2], (float)hi[2]), (T)__fsub_rn(v[3], (float)hi[3])};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1210,8 +1210,16 @@ int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C
                int32_t N, int32_t K, void* stream) {
     if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, launch_gemm16(dt_base(h->cfg.compute_dtype), epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
-                            M, N, K, (hipStream_t)stream));
+    const int dt = dt_base(h->cfg.compute_dtype);
+    if (epi & 0x100) {      // test aid: the persistent fp32-output kernel (gemm_res.hip) whatever the dispatch would choose
+        epi &= 0xff;
+        if (!gemm_res_supports(dt, epi, M, N, K)) { h->err = "mnx_gemm16: shape / epilogue not supported by gemm_res"; return MNX_ERR_INVALID_ARG; }
+        HIPCHK(h, launch_gemm_res(dt, epi, A, W, (float*)C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr, M, N, K,
+                                  (hipStream_t)stream));
+        return MNX_OK;
+    }
+    HIPCHK(h, launch_gemm16(dt, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr, M, N, K,
+                            (hipStream_t)stream));
     return MNX_OK;
 }
 
@@ -1224,6 +1232,13 @@ int mnx_gemm16_split(mnx_engine* h, int32_t epi, const void* A, int64_t a_lo, co
     HIPCHK(h, hipSetDevice(h->device));
     SplitArgs sp;
     sp.a_lo = (size_t)a_lo; sp.w_lo = (size_t)w_lo; sp.c_lo = (size_t)c_lo; sp.oscale = oscale; sp.terms = terms;
+    if (epi & 0x100) {      // test aid: gemm_res.hip whatever the dispatch would choose
+        epi &= 0xff;
+        if (!gemm_res_supports(h->cfg.compute_dtype, epi, M, N, K)) { h->err = "mnx_gemm16_split: not supported by gemm_res"; return MNX_ERR_INVALID_ARG; }
+        HIPCHK(h, launch_gemm_res(h->cfg.compute_dtype, epi, A, W, (float*)C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
+                                  M, N, K, (hipStream_t)stream, &sp));
+        return MNX_OK;
+    }
     HIPCHK(h, launch_gemm16(h->cfg.compute_dtype, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr, M, N,
                             K, (hipStream_t)stream, &sp));
     return MNX_OK;

@@ -116,6 +116,8 @@ __device__ __forceinline__ void gemm_epilogue_split(f32x4 (&acc)[BN / 32][4], ch
     constexpr int ROWB = BN * 2 + 16;
     constexpr int CH_ROW = BN * 2 / 16;
     const int tid = threadIdx.x;
+    // both planes are derived HERE, from one evaluation of every value (see split16 in common.h), and kept as 16-bit
+    v4 hi[NT][4], lo[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int nl = wn * (BN / 2) + nt * 16 + fg * 4;
@@ -125,7 +127,7 @@ __device__ __forceinline__ void gemm_epilogue_split(f32x4 (&acc)[BN / 32][4], ch
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 v = acc[nt][mt] * sp.oscale + b4;
             if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-            acc[nt][mt] = v;
+            split16x4<T>(v, hi[nt][mt], lo[nt][mt]);
         }
     }
 #pragma unroll
@@ -136,9 +138,7 @@ __device__ __forceinline__ void gemm_epilogue_split(f32x4 (&acc)[BN / 32][4], ch
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int ml = wm * 64 + mt * 16 + fr;
-                v4 hi, lo;
-                split16x4<T>(acc[nt][mt], hi, lo);
-                *(v4*)(smem + ml * ROWB + nl * 2) = plane == 0 ? hi : lo;
+                *(v4*)(smem + ml * ROWB + nl * 2) = plane == 0 ? hi[nt][mt] : lo[nt][mt];
             }
         }
         __syncthreads();
@@ -277,34 +277,56 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
         const int r = (wave * WLD + i) * 8 + r_in;
         w_src[i] = W + (size_t)min(n0 + r, N - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
     }
-    // split modes: K-tile j of the loop is term j % 3 of K-tile j / 3: (A hi, W hi), (A hi, W lo), (A lo, W hi) — the
-    // re-read of the hi tiles follows their first read immediately (L2 hits)
+    // One step of the K loop multiplies the A tile in LDS A-buffer `ia` by the W tile in W-buffer `iw` (buffer i of either
+    // operand lives in stage i: [A 128x64 | W BNx64]) while the DMA of the next step's tiles is in flight.
+    // Plain modes: step kt uses A/W buffers kt & 1 and prefetches K-tile kt + 1 into the other pair.
+    // Split modes with three terms: K-tile kt is three steps — (A hi, W hi), (A hi, W lo), (A lo, W hi) — that SHARE
+    // their fills: the hi.lo step re-uses the resident A hi tile and only W lo is fetched (into the other W buffer), the
+    // lo.hi step re-uses the resident W hi tile and only A lo is fetched (other A buffer); the next K-tile's A hi / W hi go
+    // to the buffers that the hi.lo step has finished with. 4 tile fills per 3 MFMA passes instead of 6: this loop is bound
+    // by the global -> LDS fill rate (~48 GB/s per CU measured), so that is where the split modes' time goes.
     const int nterm = SPLIT ? sp.terms : 1;
-    auto issue = [&](int j, int buf) {
+    auto issue_a = [&](size_t koff, int buf) {
         char* ab = smem + buf * STG;
-        char* wb = ab + BM * BK * 2;
-        const int kt = nterm == 3 ? j / 3 : j, term = nterm == 3 ? j - kt * 3 : 0;
-        const size_t ka = (size_t)kt * BK + (term == 2 ? sp.a_lo : 0), kw = (size_t)kt * BK + (term == 1 ? sp.w_lo : 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + ka), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + koff), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&](size_t koff, int buf) {
+        char* wb = smem + buf * STG + BM * BK * 2;
 #pragma unroll
         for (int i = 0; i < WLD; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + kw), (lds_void_t*)(wb + (wave * WLD + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + koff), (lds_void_t*)(wb + (wave * WLD + i) * 1024), 16, 0, 0);
     };
     f32x4 acc[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nk = (K / BK) * nterm;
-    issue(0, 0);
+    const int nk = K / BK, nsteps = nk * nterm;
+    issue_a(0, 0);
+    issue_w(0, 0);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* ab = smem + (kt & 1) * STG;
-        const char* wb = ab + BM * BK * 2;
+    int pa = 0, pw = 0;                    // buffers holding the current K-tile's A hi and W hi (three-term schedule)
+    for (int j = 0; j < nsteps; ++j) {
+        int ia, iw;
+        if (nterm == 3) {
+            const int kt = j / 3, term = j - kt * 3;
+            const size_t k0 = (size_t)kt * BK;
+            if (term == 0) { ia = pa; iw = pw; issue_w(k0 + sp.w_lo, pw ^ 1); }
+            else if (term == 1) { ia = pa; iw = pw ^ 1; issue_a(k0 + sp.a_lo, pa ^ 1); }
+            else {
+                ia = pa ^ 1; iw = pw;
+                if (kt + 1 < nk) { issue_a(k0 + BK, pa); issue_w(k0 + BK, pw ^ 1); }
+                pw ^= 1;                     // the next K-tile's W hi lands where this one's W lo was
+            }
+        } else {
+            ia = iw = j & 1;
+            if (j + 1 < nsteps) { issue_a((size_t)(j + 1) * BK, ia ^ 1); issue_w((size_t)(j + 1) * BK, iw ^ 1); }
+        }
+        const char* ab = smem + ia * STG;
+        const char* wb = smem + iw * STG + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             v8 af[4], wf[NT];
@@ -317,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
         }
-        __syncthreads();   // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer kt&1 for tile kt+2
+        __syncthreads();   // drains the DMA of the next step's tiles (vmcnt(0)) and frees this step's buffers
     }
     if (SPLIT) gemm_epilogue_split<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg, sp);
     else gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
@@ -457,7 +479,7 @@ hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void*
     // layers whose tile count fills the chip, the persistent 256x128 kernel for the fp32-output layers likewise, the
     // 128x128 kernel for everything else
     if (bias && gemm256_supports(dtype, epi, M, N, K)) return launch_gemm256(dtype, epi, A, W, C, bias, M, N, K, s, sp);
-    if (gemm_res_supports(dtype, epi, M, N, K)) return launch_gemm_res(dtype, epi, A, W, (float*)C, bias, resid, M, N, K, s, sp);
+    if (gemm_res_preferred(dtype, epi, M, N, K)) return launch_gemm_res(dtype, epi, A, W, (float*)C, bias, resid, M, N, K, s, sp);
     return launch_gemm16_tile128(dtype, epi, A, W, C, bias, resid, M, N, K, s, sp);
 }
 

@@ -173,19 +173,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
         T* crow = C + (size_t)(m0 + wr * 128 + (lane >> 3)) * N + n0 + wc * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
+            v4 lo[4];                                   // SPLIT: the slab's lo plane, derived together with hi (common.h split16)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                f32x4 v;
+                v4 o4;
                 if (SPLIT) {
-                    v = acc[mt][nt] * sp.oscale + b4[nt];
+                    f32x4 v = acc[mt][nt] * sp.oscale + b4[nt];
                     if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-                    acc[mt][nt] = v;                                   // kept for the lo plane
+                    split16x4<T>(v, o4, lo[nt]);
                 } else {
-                    v = acc[mt][nt] + b4[nt];
+                    f32x4 v = acc[mt][nt] + b4[nt];
                     if (EPI == EPI_GELU_16) v = gelu_fast4(v);
-                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    o4 = (v4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
                 }
-                const v4 o4 = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = o4;
             }
             // the wave's LDS operations execute in order: the reads below see the slab, the next slab's writes
@@ -198,12 +199,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
             }
             if (SPLIT) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    v4 hi, lo;
-                    split16x4<T>(acc[mt][nt], hi, lo);
-                    *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = lo;
-                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                for (int nt = 0; nt < 4; ++nt)
+                    *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = lo[nt];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = (lane >> 3) + 8 * i;

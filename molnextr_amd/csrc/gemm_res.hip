@@ -233,10 +233,17 @@ bool gemm_res_supports(int dtype, int epi, int M, int N, int K) {
     if (epi != EPI_RESID_F32 && epi != EPI_BIAS_F32) return false;
     if (M % RM || N % RN || K % RK || N > R_BIAS / 4) return false;
     if (!dt_split(dtype) && K < 2 * RK) return false;          // the residual prefetch needs >= 2 K-tiles per output tile
-    // one workgroup per CU walks tiles in rounds of 256: below one round, or when the last round is mostly empty, the
-    // 128x128 kernel (2-3 workgroups per CU) fills the chip better
-    const int tiles = (M / RM) * (N / RN), rounds = (tiles + 255) / 256;
-    return tiles >= 256 && tiles * 10 >= rounds * 256 * 7;
+    return true;
+}
+
+// Where launch_gemm16 prefers this kernel over the 128x128 one (measured per shape, profiles/r03_gemm_shapes.md):
+//   * plain 16-bit operands only — in the split modes the 128x128 kernel shares the fills of its three terms (4 tile
+//     fills per 3 MFMA passes), which this kernel's combined A|W ring does not, and wins on every shape;
+//   * >= 4 rounds of 256 tiles: one workgroup per CU walks tiles in rounds, and at 2.25 rounds (stage 4, the last
+//     patch-merging) the 128x128 kernel's 512 resident workgroups quantise no worse and run a faster K loop.
+bool gemm_res_preferred(int dtype, int epi, int M, int N, int K) {
+    if (!gemm_res_supports(dtype, epi, M, N, K) || dt_split(dtype)) return false;
+    return (M / RM) * (N / RN) >= 1024;
 }
 
 template <typename K>

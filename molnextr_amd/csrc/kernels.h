@@ -43,7 +43,8 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
                           int K, hipStream_t s, const SplitArgs* sp = nullptr);
 
 // ---- gemm_res.hip: persistent 256x128-tile form for the fp32-output epilogues (bias + fp32 residual, bias -> fp32) ----
-bool gemm_res_supports(int dtype, int epi, int M, int N, int K);  // shape / epilogue fit AND the tile count fills 256 CUs
+bool gemm_res_supports(int dtype, int epi, int M, int N, int K);   // shape / epilogue fit
+bool gemm_res_preferred(int dtype, int epi, int M, int N, int K);  // ... and measured faster than the 128x128 kernel
 hipError_t launch_gemm_res(int dtype, int epi, const void* A, const void* W, float* C, const float* bias,
                            const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp = nullptr);
 

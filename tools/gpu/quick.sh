@@ -3,8 +3,8 @@
 cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 120 python tools/gpu/diag_split_gemm.py > gpurun_out/diag_split.txt 2>&1; echo "diag rc=$?"; cat gpurun_out/diag_split.txt | cut -c1-250
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "persistent_residual or gemm_all_epilogues" > gpurun_out/t_gres.log 2>&1; echo "pytest gres rc=$?"; tail -12 gpurun_out/t_gres.log | cut -c1-300
+timeout 120 python tools/gpu/diag_split_gemm.py > gpurun_out/diag_split.txt 2>&1; echo "diag rc=$?"; grep "^epi" gpurun_out/diag_split.txt | cut -c1-250
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "gemm or swin_tiny" > gpurun_out/t_gemm.log 2>&1; echo "pytest gemm rc=$?"; tail -5 gpurun_out/t_gemm.log | cut -c1-300
 timeout 200 tools/gemm_lab/lab 128 10 - fp16x3 > gpurun_out/gemm_shapes_fp16x3_b128.txt 2>&1; cat gpurun_out/gemm_shapes_fp16x3_b128.txt | cut -c1-110
-timeout 200 tools/gemm_lab/lab 128 10 > gpurun_out/gemm_shapes_b128.txt 2>&1; cat gpurun_out/gemm_shapes_b128.txt | cut -c1-125
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub > gpurun_out/bench20.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench20.log | cut -c1-400
+timeout 900 python -m pytest tests/test_gpu_pixels.py -x -q -m gpu -k "fp16x3 or budget" > gpurun_out/t_pixels.log 2>&1; echo "pytest pixels rc=$?"; tail -3 gpurun_out/t_pixels.log | cut -c1-600
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub > gpurun_out/bench20.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench20.log | cut -c1-300
