@@ -47,20 +47,24 @@ template <> struct H16<float> {
 
 // Split-operand modes (kernels.h MNX_DT_BF16X3 / MNX_DT_F16X3): v = hi + lo up to 2^-22 |v| (fp16; the lo plane may be
 // subnormal, the MFMA does not flush 16-bit inputs) or 2^-17 |v| (bf16).
-// hi and lo MUST come from one evaluation of v: a caller that derives hi in one place and lo in another lets the compiler
-// evaluate v twice (contraction of v's producing multiply into the subtraction changes its last bit), and a v that sits on
-// a rounding tie then gets the hi of one neighbour with the lo of the other — an error of a whole 16-bit ulp (seen on
-// 3 of 384000 GELU outputs in round 3). __fsub_rn keeps the subtraction from being fused with whatever produced v.
+// hi and lo MUST be derived from the SAME fp32 value. Two things break that silently (both seen in round 3, on ~1e-5 of
+// the elements, each worth a whole 16-bit ulp): (1) deriving hi in one place and lo in another lets the compiler evaluate
+// v twice; (2) hipcc fuses `(T)(a * b)` / `(T)fma(a, b, c)` into v_fma_mixlo_f16, which rounds the EXACT product once to
+// 16 bits, while `v - (float)hi` uses the fp32-rounded v: on a near-tie hi comes from one neighbour and lo from the other.
+// The empty asm makes v an opaque fp32 register value, so hi = RN16(v) and lo = RN16(v - hi) see the same v.
 template <typename T>
 __device__ __forceinline__ void split16(float v, T& hi, T& lo) {
+    asm volatile("" : "+v"(v));
     hi = (T)v;
     lo = (T)__fsub_rn(v, (float)hi);
 }
 template <typename T>
 __device__ __forceinline__ void split16x4(f32x4 v, typename H16<T>::v4& hi, typename H16<T>::v4& lo) {
-    hi = (typename H16<T>::v4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-    lo = (typename H16<T>::v4){(T)__fsub_rn(v[0], (float)hi[0]), (T)__fsub_rn(v[1], (float)hi[1]),
-                               (T)__fsub_rn(v[2], (float)hi[2]), (T)__fsub_rn(v[3], (float)hi[3])};
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    hi = (typename H16<T>::v4){(T)a, (T)b, (T)c, (T)d};
+    lo = (typename H16<T>::v4){(T)__fsub_rn(a, (float)hi[0]), (T)__fsub_rn(b, (float)hi[1]),
+                               (T)__fsub_rn(c, (float)hi[2]), (T)__fsub_rn(d, (float)hi[3])};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
