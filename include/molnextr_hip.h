@@ -269,11 +269,12 @@ int mnx_gemm16_split(mnx_engine* h, int32_t epi, const void* A, int64_t a_lo, co
 int mnx_profile_enable(mnx_engine* h, int32_t enable);
 int mnx_profile_read(mnx_engine* h, int32_t kind, double* ms, double* work, int64_t* launches);
 
-/* Measurement aid: the two per-row attention kernels of a decode tick (self block: attention over the cache +
- * final_linear + LayerNorm + context query; cross block: attention over the projected memory + final_linear +
- * LayerNorm) launched `iters` times each between HIP events with `rows` sequences resident at position t. Isolated
- * (nothing else runs), so the algorithmic HBM bytes per launch are known exactly: rows*8*(t+1)*256 B (self K+V) and
- * rows*8*144*256 B (cross K+V). Overwrites the decoder state: not to be called while a decode call is in flight. */
+/* Measurement aid: the two attention launches of a decode layer (mnx::dec_attn_kernel over the self K/V cache, and over
+ * the projected memory K/V) launched `iters` times each between HIP events with `rows` sequences resident at position t.
+ * Launch i reads the K/V of layer i % dec_layers, exactly as the launches of a real tick do, so that one cycle touches
+ * more bytes than the 256 MB Infinity Cache holds and the time per launch is an HBM figure. Isolated (nothing else
+ * runs), so the algorithmic HBM bytes per launch are known exactly: rows*8*(t+1)*256 B (self K+V) and rows*8*144*256 B
+ * (cross K+V). Overwrites the decoder state: not to be called while a decode call is in flight. */
 int mnx_probe_decode_attn(mnx_engine* h, int32_t rows, int32_t t, int32_t iters, double* self_ms, double* cross_ms,
                           void* stream);
 

@@ -819,18 +819,31 @@ hipError_t dec_probe_attn(const DecWeights& w, const DecBuffers& b, int rows, in
     hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st);
     hipLaunchKernelGGL(dec_probe_state_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, b.st, rows, t, T);
     hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, cap);
+    // Launch i reads the K/V of LAYER i % layers, as the six attention launches of a real tick do: the bytes touched
+    // over one cycle (6 x 102 MB self at 768 rows / position 64, 6 x 226 MB cross) exceed the 256 MB Infinity Cache, so
+    // the per-launch time is an HBM figure — re-launching one layer (round 2) measured the cache instead.
+    const size_t self_layer = (size_t)b.slots * H * T * 32;
     AttnArgs at = {};
-    at.q = b.q; at.K = b.self_k; at.V = b.self_v; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
+    at.q = b.q; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
     at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32;
-    hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);      // warm-up
+    auto self_launch = [&](int i) {
+        const int l = i % w.layers;
+        at.K = b.self_k + (size_t)l * self_layer; at.V = b.self_v + (size_t)l * self_layer;
+        hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);
+    };
+    for (int i = 0; i < w.layers; ++i) self_launch(i);                                     // warm-up: one full cycle
     hipError_t e = hipEventRecord(ev[0], s);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);
+    for (int i = 0; i < iters; ++i) self_launch(i);
     if (e == hipSuccess) e = hipEventRecord(ev[1], s);
-    at.K = b.mem_kv; at.V = at.K + (size_t)b.S * D;
     at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = (long long)b.S * 32; at.fixed_keys = b.S; at.cross = 1;
-    hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);      // warm-up
+    auto cross_launch = [&](int i) {
+        const int l = i % w.layers;
+        at.K = b.mem_kv + (size_t)l * 2 * b.S * D; at.V = at.K + (size_t)b.S * D;
+        hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);
+    };
+    for (int i = 0; i < w.layers; ++i) cross_launch(i);                                    // warm-up
     if (e == hipSuccess) e = hipEventRecord(ev[2], s);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);
+    for (int i = 0; i < iters; ++i) cross_launch(i);
     if (e == hipSuccess) e = hipEventRecord(ev[3], s);
     hipLaunchKernelGGL(dec_reset_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st);
     return e != hipSuccess ? e : hipGetLastError();
