@@ -296,6 +296,299 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
     if (wr == 0) __builtin_amdgcn_s_barrier();    // the first wave row waits for the second one's last segment
 }
 
+// =====================================================================================================================
+// gemm256x3_kernel — the split-operand form with all three product terms (dtypes BF16X3 / F16X3, SplitArgs::terms == 3).
+//
+// gemm256_kernel<.., SPLIT> streams the three terms of a K-tile as three complete K-tiles: 12 slot fills and 72 fragment
+// reads per 192 MFMAs of a wave, although A hi and W hi are each needed twice. This kernel keeps the four operand slabs of
+// ONE K-tile resident — the 8 ring slots are A hi (2), A lo (2), W hi (2), W lo (2) — and walks the six 32-MFMA products
+// of the tile in an order in which consecutive products share one register operand:
+//
+//     phase  product      fragments read (LDS)            slot refilled at the START of the phase (read last in the
+//                                                          phase before)                       wait for (next phase)
+//     P1     Ah0 . Wh     Ah0 (8) + Wh (8)                A lo, rows 0-63   of THIS K-tile       W lo
+//     P2     Ah0 . Wl     Wl (8)   [Ah0 stays in regs]    A hi, rows 0-63   of the NEXT K-tile   Ah1
+//     P3     Ah1 . Wl     Ah1 (8)  [Wl stays]             W lo (both halves) of the next          —  (Wh landed before P1)
+//     P4     Ah1 . Wh     Wh (8)   [Ah1 stays]            A hi, rows 64-127 of the next          Al1
+//     P5     Al1 . Wh     Al1 (8)  [Wh stays]             W hi (both halves) of the next          Al0
+//     P6     Al0 . Wh     Al0 (8)  [Wh stays]             A lo, rows 64-127 of the next          Ah0', Wh' of the next
+//
+// (rows = the first / second 64 rows of each wave-row block, as the Am0 / Am1 slots of gemm256_kernel; the W slots are its
+// Bn0 / Bn1.) 8 slot fills and 56 fragment reads per 192 MFMAs. Every slot is single-buffered: it is refilled in the phase
+// after its last read and needed again 5 phases later — except W hi (read in P1 and P4, refilled in P5, needed in P1: 2
+// phases), which is the operand that every M-tile of the launch shares and therefore always comes from L2.
+// Phase skeleton, barrier pairing of the two wave rows (half a phase apart) and the epilogue are those of gemm256_kernel:
+// a slot read in phase n may be overwritten from the start of phase n + 1 (the other row passed its opening barrier of
+// phase n, after its reads); data read in phase n + 1 is waited for (counted vmcnt) before the opening barrier of phase n.
+// vmcnt: a wave issues 16 fill instructions per K-tile in the order P1: 2, P2: 2, P3: 4, P4: 2, P5: 4, P6: 2; the number
+// of younger operations allowed at each wait is derived below. First K-tile of the stream and last K-tile of the stream
+// (different in-flight population) drain instead of counting.
+// one 16-byte-per-lane LDS-DMA: LDS[lds + 16 lane] <- sbase[voff] (scalar base, 32-bit lane offset: no 64-bit VGPR address;
+// the builtin form made hipcc keep a zero-extended 64-bit copy of every lane offset and spill them — scratch traffic
+// would also break the vmcnt bookkeeping). M0 (the LDS address of an LDS-DMA) is a reserved register that the compiler
+// neither tracks nor preserves around inline asm: gemm256x3_kernel therefore issues EVERY LDS-DMA through these helpers
+// and uses nothing else that reads M0 (tests/test_device_math.py checks the generated ISA for both).
+__device__ __forceinline__ void dma16(unsigned voff, const char* sbase, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma4(unsigned voff, const char* sbase, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+constexpr int X3_BIAS = 1;                                 // one 4-byte-per-lane DMA per wave per tile (its 64 bias values)
+constexpr int X3_LDS = P_LDS + 8 * 256;                    // + a 256-byte bias patch per wave
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A, const T* __restrict__ W, T* __restrict__ C,
+                                                         const float* __restrict__ bias, int M, int N, int K, int tiles_n,
+                                                         int n_tiles, const SplitArgs sp) {
+    static_assert(EPI == EPI_BIAS_16 || EPI == EPI_GELU_16, "persistent form: 16-bit outputs only");
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    constexpr int PST = 2 * P_STORES;                       // two output planes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / TK;
+    const int my_first = blockIdx.x, stride = gridDim.x;
+    const int my_tiles = (n_tiles - my_first + stride - 1) / stride;
+    const int total_kt = my_tiles * nk;
+    const long a_lo_b = (long)sp.a_lo * 2, w_lo_b = (long)sp.w_lo * 2;
+    enum { S_AH0 = 0, S_AH1 = 1, S_AL0 = 2, S_AL1 = 3, S_WH0 = 4, S_WH1 = 5, S_WL0 = 6, S_WL1 = 7 };
+
+    // DMA addressing: a wave fills two 1 KiB pieces (8 rows x 128 B) of every slot. The lane part of a piece's source
+    // offset is the same for both 64-row halves of A (both 32-row halves of W): the half is a scalar addend on the base.
+    const int r_in = lane >> 3, pc = lane & 7;
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = (wave * 2 + i) * 8 + r_in;
+        const int sw = (pc ^ ((s >> 1) & 7)) << 3;
+        offA[i] = (unsigned)((((s >> 6) * 128 + (s & 63)) * K + sw) * 2);
+        offB[i] = (unsigned)((((s >> 5) * 64 + (s & 31)) * K + sw) * 2);
+    }
+    const long halfA_b = (long)64 * K * 2, halfB_b = (long)32 * K * 2;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_char_t*)smem + (unsigned)(wave * 2048);   // the wave's first piece of slot 0
+    struct Pos { const char* a; const char* w; int kt, seq; };      // hi planes of one K-tile
+    auto tile_origin = [&](int seq, int& m0, int& n0) {
+        const int tile = xcd_remap(my_first + seq * stride, n_tiles);
+        m0 = (tile / tiles_n) * TM; n0 = (tile % tiles_n) * TN;
+    };
+    auto pos_at = [&](int seq) {
+        int m0, n0; tile_origin(seq, m0, n0);
+        Pos q; q.a = (const char*)(A + (size_t)m0 * K); q.w = (const char*)(W + (size_t)n0 * K); q.kt = 0; q.seq = seq;
+        return q;
+    };
+    auto advance = [&](Pos& q) {
+        if (++q.kt == nk) { if (q.seq + 1 < my_tiles) q = pos_at(q.seq + 1); else { q.kt = 0; ++q.seq; } }
+        else { q.a += TK * 2; q.w += TK * 2; }
+    };
+    auto fill_a = [&](const char* base, int half, int slot) {       // 64-row half of every wave-row block -> one slot
+        const char* b = base + half * halfA_b;
+        dma16(offA[0], b, lds0 + slot * SLOT);
+        dma16(offA[1], b, lds0 + slot * SLOT + 1024);
+    };
+    auto fill_w = [&](const char* base, int slot0) {                // both 32-row halves of every wave-column block -> two slots
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const char* b = base + h * halfB_b;
+            dma16(offB[0], b, lds0 + (slot0 + h) * SLOT);
+            dma16(offB[1], b, lds0 + (slot0 + h) * SLOT + 1024);
+        }
+    };
+    // bias of the tile being accumulated: the wave's 64 values, DMA'd into its own 256-byte LDS patch at the tile's first
+    // K-tile (one more entry of the in-order vmcnt queue, retired by the counted waits) and read in the epilogue
+    const float* bias_s = (const float*)(smem + P_LDS + wave * 256);
+    const unsigned bias_lds = (unsigned)(__UINTPTR_TYPE__)(lds_char_t*)smem + (unsigned)(P_LDS + wave * 256);
+    auto load_bias = [&](int n0) { dma4((unsigned)(lane * 4), (const char*)(bias + n0 + wc * 64), bias_lds); };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int m0, n0;
+    tile_origin(0, m0, n0);
+    load_bias(n0);
+    Pos cur = pos_at(0);
+    // prologue: everything K-tile 0 needs except A lo rows 0-63 (issued by its own P1), in the order of first use
+    fill_a(cur.a, 0, S_AH0); fill_w(cur.w, S_WH0); fill_w(cur.w + w_lo_b, S_WL0); fill_a(cur.a, 1, S_AH1);
+    fill_a(cur.a + a_lo_b, 1, S_AL1);
+    Pos nxt = cur;
+    advance(nxt);
+    wait_vm<8>();                                 // bias, Ah0, Wh landed (W lo 4 + Ah1 2 + Al1 2 may fly)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row starts one segment late
+
+    char* stg = smem + 8 * SLOT + wave * P_STG;
+    v8 af[4][2], b0[2][2], b1[2][2];
+    // fragment addresses: the swizzle term of lds_off256 depends on (row >> 1) & 7 = (fr >> 1) & 7 only, so the 16-row
+    // tile index and the slot are immediate offsets on two lane-dependent bases per operand (one per 32-wide K half)
+    const char* a_rd[2];
+    const char* w_rd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_rd[ks] = smem + lds_off256(wr * 64 + fr, ks * 4 + fg);
+        w_rd[ks] = smem + S_WH0 * SLOT + lds_off256(wc * 32 + fr, ks * 4 + fg);
+    }
+    auto read_a = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const v8*)(a_rd[ks] + slot * SLOT + i * 2048);
+    };
+    auto read_w = [&](auto slot_c) {
+        constexpr int rel = decltype(slot_c)::value - S_WH0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                b0[j][ks] = *(const v8*)(w_rd[ks] + rel * SLOT + j * 2048);
+                b1[j][ks] = *(const v8*)(w_rd[ks] + (rel + 1) * SLOT + j * 2048);
+            }
+    };
+    using R_AH0 = std::integral_constant<int, S_AH0>;
+    using R_AH1 = std::integral_constant<int, S_AH1>;
+    using R_AL0 = std::integral_constant<int, S_AL0>;
+    using R_AL1 = std::integral_constant<int, S_AL1>;
+    using R_WH = std::integral_constant<int, S_WH0>;
+    using R_WL = std::integral_constant<int, S_WL0>;
+    // the 32 MFMAs of one phase: rows [mb*16, mb*16 + 64) of the wave tile += af . (b0 | b1)
+    auto mfma_block = [&](auto mb_c) {
+        constexpr int mb = decltype(mb_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[mb + i][j] = H16<T>::mfma(b0[j][ks], af[i][ks], acc[mb + i][j]);
+                    acc[mb + i][2 + j] = H16<T>::mfma(b1[j][ks], af[i][ks], acc[mb + i][2 + j]);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using MB0 = std::integral_constant<int, 0>;
+    using MB4 = std::integral_constant<int, 4>;
+    auto epilogue = [&]() {
+        // ---- epilogue of the finished tile: 16-row slabs through the wave's own staging patch, hi plane then lo plane ----
+        f32x4 b4[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) b4[nt] = *(const f32x4*)(bias_s + nt * 16 + fg * 4);
+        T* crow = C + (size_t)(m0 + wr * 128 + (lane >> 3)) * N + n0 + wc * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            v4 lo[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 v = acc[mt][nt] * sp.oscale + b4[nt];
+                if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                v4 hi;
+                split16x4<T>(v, hi, lo[nt]);
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = hi;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (lane >> 3) + 8 * i;
+                const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                *(v8*)(crow + (size_t)(mt * 16 + 8 * i) * N) = o8;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = lo[nt];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (lane >> 3) + 8 * i;
+                const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                *(v8*)(crow + sp.c_lo + (size_t)(mt * 16 + 8 * i) * N) = o8;
+            }
+        }
+    };
+    // counted wait of one phase. `normal` = younger fill instructions at this point of a steady K-tile; in the FIRST K-tile
+    // of an output tile (not the stream's first) the epilogue's PST stores and / or the bias DMA (X3_BIAS) are younger too.
+    // drain: first / last K-tile of the stream.
+#define MNX_X3_WAIT(normal, extra_first)                                         \
+    do {                                                                          \
+        if (drain) wait_vm<0>();                                                  \
+        else if (first_kt) wait_vm<(normal) + (extra_first)>();                   \
+        else wait_vm<(normal)>();                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
+        __builtin_amdgcn_s_barrier();                                             \
+    } while (0)
+
+    int kt = 0, seq = 0;
+    for (int g = 0; g < total_kt; ++g) {
+        const bool last_kt = (kt == nk - 1);
+        const bool has_next = g + 1 < total_kt;
+        const bool first_kt = (kt == 0 && seq > 0);
+        const bool drain = (g == 0) || !has_next;
+        // ---- P1: Ah0 . Wh -> rows 0..63.   refill: A lo rows 0-63 of THIS K-tile (its slot was read last in P6)
+        fill_a(cur.a + a_lo_b, 0, S_AL0);
+        if (first_kt) load_bias(n0);
+        read_a(R_AH0{});
+        read_w(R_WH{});
+        // W lo (issued in P3 of the previous K-tile). Younger: P4 2, P5 4, P6 2 [, PST stores], this phase's 2 [+ bias]
+        MNX_X3_WAIT(10, PST + X3_BIAS);
+        mfma_block(MB0{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P2: Ah0 . Wl -> rows 0..63.   refill: A hi rows 0-63 of the next K-tile
+        if (has_next) fill_a(nxt.a, 0, S_AH0);
+        read_w(R_WL{});
+        // Ah1 (issued in P4 of the previous K-tile). Younger: P5 4, P6 2 [, PST stores], P1 2 [+ bias], P2 2
+        MNX_X3_WAIT(10, PST + X3_BIAS);
+        mfma_block(MB0{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P3: Ah1 . Wl -> rows 64..127.   refill: W lo of the next K-tile.   P4 re-reads W hi: landed before P1
+        if (has_next) fill_w(nxt.w + w_lo_b, S_WL0);
+        read_a(R_AH1{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma_block(MB4{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P4: Ah1 . Wh -> rows 64..127.   refill: A hi rows 64-127 of the next K-tile
+        if (has_next) fill_a(nxt.a, 1, S_AH1);
+        read_w(R_WH{});
+        // Al1 (issued in P6 of the previous K-tile, before its epilogue). Younger: [PST stores,] P1 2 [+ bias], P2 2, P3 4, P4 2
+        MNX_X3_WAIT(10, PST + X3_BIAS);
+        mfma_block(MB4{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P5: Al1 . Wh -> rows 64..127.   refill: W hi of the next K-tile
+        if (has_next) fill_w(nxt.w, S_WH0);
+        read_a(R_AL1{});
+        // Al0 (issued in P1 of this K-tile, before the bias loads). Younger: [bias,] P2 2, P3 4, P4 2, P5 4
+        MNX_X3_WAIT(12, X3_BIAS);
+        mfma_block(MB4{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P6: Al0 . Wh -> rows 0..63.   refill: A lo rows 64-127 of the next K-tile
+        if (has_next) fill_a(nxt.a + a_lo_b, 1, S_AL1);
+        read_a(R_AL0{});
+        // Ah0', Wh' of the next K-tile (issued in P2 / P5). Younger than Wh': this phase's 2
+        MNX_X3_WAIT(2, 0);
+        mfma_block(MB0{});
+        // epilogue placement as gemm256_kernel: second wave row before its closing barrier, first row after its own
+        if (last_kt && wr == 1) epilogue();
+        __builtin_amdgcn_s_barrier();
+        if (last_kt && wr == 0) epilogue();
+        cur = nxt;
+        advance(nxt);
+        if (last_kt) {
+            kt = 0; ++seq;
+            if (seq < my_tiles) tile_origin(seq, m0, n0);
+        } else {
+            ++kt;
+        }
+    }
+#undef MNX_X3_WAIT
+    if (wr == 0) __builtin_amdgcn_s_barrier();    // the first wave row waits for the second one's last segment
+}
+
 }  // namespace
 
 bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
@@ -311,13 +604,13 @@ bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
 // The 144 KiB dynamic-LDS opt-in is a per-device, per-function attribute: set once per (device, instantiation), so that
 // several handles on different GPUs of one process all get it (include/molnextr_hip.h allows that).
 template <typename K>
-static hipError_t lds_opt_in(K kernel) {
+static hipError_t lds_opt_in(K kernel, int lds_bytes = P_LDS) {
     static unsigned long long done = 0;          // bit d: device d has the attribute (<= 64 devices per process)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
     return e;
 }
@@ -340,11 +633,27 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
     }
 #define MNX_G256_TYPE(TT, SP)                                                                                             \
     switch (epi) { MNX_G256_CASE(TT, EPI_BIAS_16, SP) MNX_G256_CASE(TT, EPI_GELU_16, SP) default: return hipErrorInvalidValue; }
+#define MNX_G256X3_CASE(TT, E)                                                                                            \
+    case E: {                                                                                                             \
+        const hipError_t attr = lds_opt_in(gemm256x3_kernel<TT, E>, X3_LDS);                                              \
+        if (attr != hipSuccess) return attr;                                                                              \
+        hipLaunchKernelGGL((gemm256x3_kernel<TT, E>), dim3(grid), dim3(512), X3_LDS, s, (const TT*)A, (const TT*)W,       \
+                           (TT*)C, bias, M, N, K, tn, tm * tn, spv);                                                      \
+        break;                                                                                                            \
+    }
+#define MNX_G256X3_TYPE(TT)                                                                                               \
+    switch (epi) { MNX_G256X3_CASE(TT, EPI_BIAS_16) MNX_G256X3_CASE(TT, EPI_GELU_16) default: return hipErrorInvalidValue; }
+    if (split && spv.terms == 3) {      // all three terms: the shared-fill six-phase kernel
+        if (dtype == MNX_DT_F16X3) { MNX_G256X3_TYPE(f16_t) } else { MNX_G256X3_TYPE(bf16_t) }
+        return hipGetLastError();
+    }
     if (dtype == MNX_DT_F16) { MNX_G256_TYPE(f16_t, false) }
     else if (dtype == MNX_DT_BF16) { MNX_G256_TYPE(bf16_t, false) }
     else if (dtype == MNX_DT_F16X3) { MNX_G256_TYPE(f16_t, true) }
     else if (dtype == MNX_DT_BF16X3) { MNX_G256_TYPE(bf16_t, true) }
     else return hipErrorInvalidValue;
+#undef MNX_G256X3_TYPE
+#undef MNX_G256X3_CASE
 #undef MNX_G256_TYPE
 #undef MNX_G256_CASE
     return hipGetLastError();

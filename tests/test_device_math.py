@@ -61,3 +61,32 @@ def test_gemm256_vmcnt_bookkeeping_constants():
     bias = bias[:bias.index("    };\n")]
     assert "for (int nt = 0; nt < 4; ++nt)" in bias and bias.count("global_load_dwordx4") == 1
     assert src.count("wait_vm<8 + PST + P_BIAS>()") == 2 and src.count("wait_vm<8 + P_BIAS>()") == 1
+
+
+def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
+    """gemm256x3_kernel (gemm256.hip) counts vector-memory operations by hand (s_waitcnt vmcnt(N)) and issues its LDS-DMA
+    through inline asm that writes M0, a register the compiler does not track around asm. Both only hold if the generated
+    code (1) has no scratch (spill) traffic — scratch loads / stores are vector-memory operations too —, (2) touches M0
+    nowhere but in the `s_mov_b32 m0` in front of each of those DMA instructions, and (3) contains no wait the compiler
+    added on its own: exactly the five vmcnt(0) of the drain branches."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "molnextr_amd", "csrc", "gemm256.hip")
+    out = tmp_path / "gemm256.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN3mnx12_GLOBAL__N_116gemm256x3_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 4                                   # {fp16, bf16} x {bias, bias + GELU}
+    for name, body in kernels:
+        assert "scratch_" not in body, name
+        n_dma = len(re.findall(r"global_load_lds_dword", body))
+        assert n_dma == 32, (name, n_dma)                      # prologue 15 + 1 bias in P1 + 16 per K-tile
+        assert len(re.findall(r"\bm0\b", body)) == n_dma == len(re.findall(r"s_mov_b32 m0,", body)), name
+        waits = sorted(int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
+        assert waits == [0, 0, 0, 0, 0, 2, 2, 8, 10, 10, 10, 12, 13, 43, 43, 43], (name, waits)
+        assert len(re.findall(r"s_barrier", body)) == 15, name
