@@ -340,13 +340,16 @@ constexpr int X3_BIAS = 1;                                 // one 4-byte-per-lan
 constexpr int X3_LDS = P_LDS + 8 * 256;                    // + a 256-byte bias patch per wave
 
 template <typename T, int EPI>
-__global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A, const T* __restrict__ W, T* __restrict__ C,
-                                                         const float* __restrict__ bias, int M, int N, int K, int tiles_n,
-                                                         int n_tiles, const SplitArgs sp) {
-    static_assert(EPI == EPI_BIAS_16 || EPI == EPI_GELU_16, "persistent form: 16-bit outputs only");
+__global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cv,
+                                                         const float* __restrict__ bias, const float* resid, int M, int N,
+                                                         int K, int tiles_n, int n_tiles, const SplitArgs sp) {
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
-    constexpr int PST = 2 * P_STORES;                       // two output planes
+    constexpr bool OUT16 = (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16);
+    // vector-memory operations of a tile's epilogue per wave: two 16-bit planes x 16 stores; fp32 output 32 stores
+    // (+ 32 residual loads)
+    constexpr int PST = OUT16 ? 2 * P_STORES : (EPI == EPI_RESID_F32 ? 64 : 32);
+    T* C = (T*)Cv;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     const float* bias_s = (const float*)(smem + P_LDS + wave * 256);
     const unsigned bias_lds = (unsigned)(__UINTPTR_TYPE__)(lds_char_t*)smem + (unsigned)(P_LDS + wave * 256);
     auto load_bias = [&](int n0) { dma4((unsigned)(lane * 4), (const char*)(bias + n0 + wc * 64), bias_lds); };
+    // (a layer without bias — the patch-merging reduction — passes a zero vector: launch_gemm256x3 substitutes one)
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -477,10 +481,35 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     using MB0 = std::integral_constant<int, 0>;
     using MB4 = std::integral_constant<int, 4>;
     auto epilogue = [&]() {
-        // ---- epilogue of the finished tile: 16-row slabs through the wave's own staging patch, hi plane then lo plane ----
         f32x4 b4[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) b4[nt] = *(const f32x4*)(bias_s + nt * 16 + fg * 4);
+        if (!OUT16) {
+            // ---- fp32 output (+ in-place fp32 residual): straight from the accumulators. A lane owns 4 consecutive columns
+            // of row fr of every 16-row slab: 16-byte accesses, the 4 lane groups of a row cover 64 contiguous bytes. Every
+            // element is read and written by the same lane, so C may alias the residual. The loads and stores are ordinary
+            // (compiler-tracked) operations: its waits can only be stricter than needed here (they also drain the fills in
+            // flight, which are older), never too weak.
+            float* cp = (float*)Cv + (size_t)(m0 + wr * 128 + fr) * N + n0 + wc * 64 + fg * 4;
+            const float* rp = resid + (size_t)(m0 + wr * 128 + fr) * N + n0 + wc * 64 + fg * 4;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                f32x4 v[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    v[nt] = acc[mt][nt] * sp.oscale + b4[nt];
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (EPI == EPI_RESID_F32) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) v[nt] += *(const f32x4*)(rp + (size_t)mt * 16 * N + nt * 16);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) *(f32x4*)(cp + (size_t)mt * 16 * N + nt * 16) = v[nt];
+            }
+            return;
+        }
+        // ---- 16-bit output: 16-row slabs through the wave's own staging patch, hi plane then lo plane ----
         T* crow = C + (size_t)(m0 + wr * 128 + (lane >> 3)) * N + n0 + wc * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
@@ -517,7 +546,7 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 #define MNX_X3_WAIT(normal, extra_first)                                         \
     do {                                                                          \
         if (drain) wait_vm<0>();                                                  \
-        else if (first_kt) wait_vm<(normal) + (extra_first)>();                   \
+        else if (first_kt) wait_vm<((normal) + (extra_first) > 63 ? 63 : (normal) + (extra_first))>();   /* vmcnt is 6 bits */ \
         else wait_vm<(normal)>();                                                 \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
         __builtin_amdgcn_s_barrier();                                             \
@@ -591,16 +620,6 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 
 }  // namespace
 
-bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
-    if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16 && !dt_split(dtype)) return false;
-    if (epi != EPI_BIAS_16 && epi != EPI_GELU_16) return false;
-    if (M % TM || N % TN || K % TK || K < 2 * TK) return false;
-    // one workgroup per CU walks tiles in rounds of 256: below one round, or when the last round is mostly empty, the
-    // 128x128 kernel fills the chip better
-    const int tiles = (M / TM) * (N / TN), rounds = (tiles + 255) / 256;
-    return tiles >= 256 && tiles * 10 >= rounds * 256 * 7;
-}
-
 // The 144 KiB dynamic-LDS opt-in is a per-device, per-function attribute: set once per (device, instantiation), so that
 // several handles on different GPUs of one process all get it (include/molnextr_hip.h allows that).
 template <typename K>
@@ -613,6 +632,63 @@ static hipError_t lds_opt_in(K kernel, int lds_bytes = P_LDS) {
     e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
     return e;
+}
+
+// gemm256x3_kernel: split dtypes, any of the four epilogues, whole 256x256 tiles, >= 2 K-tiles.
+bool gemm256x3_supports(int dtype, int epi, int M, int N, int K) {
+    if (!dt_split(dtype)) return false;
+    if (epi != EPI_BIAS_16 && epi != EPI_GELU_16 && epi != EPI_RESID_F32 && epi != EPI_BIAS_F32) return false;
+    return M > 0 && M % TM == 0 && N % TN == 0 && K % TK == 0 && K >= 2 * TK;
+}
+
+static const float* zero_bias(int n) {      // per-device zero vector for layers without a bias (<= 4096 columns)
+    static const float* z[64] = {};
+    int dev = 0;
+    if (n > 4096 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!z[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 4096 * sizeof(float)) != hipSuccess || hipMemset(p, 0, 4096 * sizeof(float)) != hipSuccess) return nullptr;
+        z[dev] = (const float*)p;
+    }
+    return z[dev];
+}
+
+hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                            const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
+    if (!sp || sp->terms != 3 || !gemm256x3_supports(dtype, epi, M, N, K)) return hipErrorInvalidValue;
+    if (epi == EPI_RESID_F32 && !resid) return hipErrorInvalidValue;
+    if (!bias && !(bias = zero_bias(N))) return hipErrorInvalidValue;
+    const SplitArgs spv = *sp;
+    const int tm = M / TM, tn = N / TN;
+    const int grid = tm * tn < 256 ? tm * tn : 256;
+#define MNX_G256X3_CASE(TT, E)                                                                                            \
+    case E: {                                                                                                             \
+        const hipError_t attr = lds_opt_in(gemm256x3_kernel<TT, E>, X3_LDS);                                              \
+        if (attr != hipSuccess) return attr;                                                                              \
+        hipLaunchKernelGGL((gemm256x3_kernel<TT, E>), dim3(grid), dim3(512), X3_LDS, s, (const TT*)A, (const TT*)W, C,    \
+                           bias, resid, M, N, K, tn, tm * tn, spv);                                                       \
+        break;                                                                                                            \
+    }
+#define MNX_G256X3_TYPE(TT)                                                                                               \
+    switch (epi) {                                                                                                        \
+        MNX_G256X3_CASE(TT, EPI_BIAS_16) MNX_G256X3_CASE(TT, EPI_GELU_16) MNX_G256X3_CASE(TT, EPI_RESID_F32)              \
+        MNX_G256X3_CASE(TT, EPI_BIAS_F32)                                                                                 \
+        default: return hipErrorInvalidValue;                                                                             \
+    }
+    if (dtype == MNX_DT_F16X3) { MNX_G256X3_TYPE(f16_t) } else { MNX_G256X3_TYPE(bf16_t) }
+#undef MNX_G256X3_TYPE
+#undef MNX_G256X3_CASE
+    return hipGetLastError();
+}
+
+bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
+    if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16 && !dt_split(dtype)) return false;
+    if (epi != EPI_BIAS_16 && epi != EPI_GELU_16) return false;
+    if (M % TM || N % TN || K % TK || K < 2 * TK) return false;
+    // one workgroup per CU walks tiles in rounds of 256: below one round, or when the last round is mostly empty, the
+    // 128x128 kernel fills the chip better
+    const int tiles = (M / TM) * (N / TN), rounds = (tiles + 255) / 256;
+    return tiles >= 256 && tiles * 10 >= rounds * 256 * 7;
 }
 
 hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
@@ -633,27 +709,13 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
     }
 #define MNX_G256_TYPE(TT, SP)                                                                                             \
     switch (epi) { MNX_G256_CASE(TT, EPI_BIAS_16, SP) MNX_G256_CASE(TT, EPI_GELU_16, SP) default: return hipErrorInvalidValue; }
-#define MNX_G256X3_CASE(TT, E)                                                                                            \
-    case E: {                                                                                                             \
-        const hipError_t attr = lds_opt_in(gemm256x3_kernel<TT, E>, X3_LDS);                                              \
-        if (attr != hipSuccess) return attr;                                                                              \
-        hipLaunchKernelGGL((gemm256x3_kernel<TT, E>), dim3(grid), dim3(512), X3_LDS, s, (const TT*)A, (const TT*)W,       \
-                           (TT*)C, bias, M, N, K, tn, tm * tn, spv);                                                      \
-        break;                                                                                                            \
-    }
-#define MNX_G256X3_TYPE(TT)                                                                                               \
-    switch (epi) { MNX_G256X3_CASE(TT, EPI_BIAS_16) MNX_G256X3_CASE(TT, EPI_GELU_16) default: return hipErrorInvalidValue; }
-    if (split && spv.terms == 3) {      // all three terms: the shared-fill six-phase kernel
-        if (dtype == MNX_DT_F16X3) { MNX_G256X3_TYPE(f16_t) } else { MNX_G256X3_TYPE(bf16_t) }
-        return hipGetLastError();
-    }
+    if (split && spv.terms == 3)        // all three terms: the shared-fill six-phase kernel
+        return launch_gemm256x3(dtype, epi, A, W, C, bias, nullptr, M, N, K, s, sp);
     if (dtype == MNX_DT_F16) { MNX_G256_TYPE(f16_t, false) }
     else if (dtype == MNX_DT_BF16) { MNX_G256_TYPE(bf16_t, false) }
     else if (dtype == MNX_DT_F16X3) { MNX_G256_TYPE(f16_t, true) }
     else if (dtype == MNX_DT_BF16X3) { MNX_G256_TYPE(bf16_t, true) }
     else return hipErrorInvalidValue;
-#undef MNX_G256X3_TYPE
-#undef MNX_G256X3_CASE
 #undef MNX_G256_TYPE
 #undef MNX_G256_CASE
     return hipGetLastError();

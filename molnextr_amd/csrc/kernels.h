@@ -41,6 +41,12 @@ hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* 
 bool gemm256_supports(int dtype, int epi, int M, int N, int K);   // shape / epilogue fit AND the tile count fills 256 CUs
 hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
                           int K, hipStream_t s, const SplitArgs* sp = nullptr);
+// gemm256x3_kernel (gemm256.hip): split dtypes with all three terms, any epilogue, M and N multiples of 256. Runs EVERY
+// tile it is given on one workgroup per CU in rounds of 256: launch_gemm16 hands it whole rounds and the 128x128 kernel
+// the remaining rows.
+bool gemm256x3_supports(int dtype, int epi, int M, int N, int K);
+hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                            const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp);
 
 // ---- gemm_res.hip: persistent 256x128-tile form for the fp32-output epilogues (bias + fp32 residual, bias -> fp32) ----
 bool gemm_res_supports(int dtype, int epi, int M, int N, int K);   // shape / epilogue fit

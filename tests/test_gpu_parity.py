@@ -85,7 +85,8 @@ def _split_planes(x, td, scale=1.0):
                                    (16384, 1024, 256), (18432, 2048, 512), (65536, 256, 128)])
 def test_gemm_split_operand_modes(dev, dtype, M, N, K):
     """The split-operand GEMM (hi.hi + hi.lo + lo.hi on the 16-bit MFMA) of both kernels — 128-tile (DMA and non-DMA K
-    loops) and the persistent 256x256 one (last three shapes, 16-bit-output epilogues) — against a float64 product of the
+    loops) and the six-phase persistent 256x256 one (gemm256x3_kernel: the last three shapes, all four epilogues; the
+    576-tile shape splits into 2 whole rounds on it + the remaining rows on the 128-tile kernel) — against a float64 product of the
     SAME fp32 inputs, every output element: fp32-class accuracy from 16-bit matrix instructions, the exact-erf GELU, the
     hi + lo output planes, the power-of-two weight scale, and terms = 1 degrading to the plain 16-bit product."""
     e = _tiny_engine(dtype)
@@ -102,10 +103,16 @@ def test_gemm_split_operand_modes(dev, dtype, M, N, K):
     out = torch.zeros(M, N, device=dev)
     e.gemm16_split(3, A2, W2, out, bias, oscale=1.0 / wscale)
     assert (out.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    out.fill_(7.0)
+    e.gemm16_split(3, A2, W2, out, None, oscale=1.0 / wscale)          # a layer without bias (patch-merging reduction)
+    assert (out.double() - (ref - bias.double())).abs().max().item() < tol * max(1.0, ref.abs().max().item())
     res = torch.randn(M, N, generator=g).to(dev)
     r2 = res.clone()
     e.gemm16_split(2, A2, W2, r2, bias, oscale=1.0 / wscale)
     assert (r2.double() - (ref + res.double())).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    again = res.clone()
+    e.gemm16_split(2, A2, W2, again, bias, oscale=1.0 / wscale)
+    assert torch.equal(again, r2)                                       # same launch twice: bit-identical
     for epi, want in ((0, ref), (1, torch.nn.functional.gelu(ref))):
         o2 = torch.zeros(2, M, N, device=dev, dtype=td)
         e.gemm16_split(epi, A2, W2, o2, bias, oscale=1.0 / wscale)
