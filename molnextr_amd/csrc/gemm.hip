@@ -255,9 +255,12 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     typedef typename H16<T>::v8 v8;
     constexpr int NT = BN / 32;
     constexpr int WLD = BN / 32;
-    constexpr int STG = (BM + BN) * BK * 2;
+    constexpr int ASZ = BM * BK * 2, WSZ = BN * BK * 2;        // one A tile (16 KiB), one W tile
     constexpr int EPI_LDS = 34816;    // largest epilogue staging area: 128 rows x (128 x 2 + 16) B = 128 x (64 x 4 + 16) B
-    __shared__ __attribute__((aligned(16))) char smem[2 * STG > EPI_LDS ? 2 * STG : EPI_LDS];
+    // LDS: two A buffers, then two (plain modes) or three (split modes) W buffers
+    constexpr int NWB = SPLIT ? 3 : 2;
+    constexpr int RING = 2 * ASZ + NWB * WSZ;
+    __shared__ __attribute__((aligned(16))) char smem[RING > EPI_LDS ? RING : EPI_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -277,23 +280,28 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
         const int r = (wave * WLD + i) * 8 + r_in;
         w_src[i] = W + (size_t)min(n0 + r, N - 1) * K + ((p ^ ((r >> 1) & 7)) << 3);
     }
-    // One step of the K loop multiplies the A tile in LDS A-buffer `ia` by the W tile in W-buffer `iw` (buffer i of either
-    // operand lives in stage i: [A 128x64 | W BNx64]) while the DMA of the next step's tiles is in flight.
-    // Plain modes: step kt uses A/W buffers kt & 1 and prefetches K-tile kt + 1 into the other pair.
-    // Split modes with three terms: K-tile kt is three steps — (A hi, W hi), (A hi, W lo), (A lo, W hi) — that SHARE
-    // their fills: the hi.lo step re-uses the resident A hi tile and only W lo is fetched (into the other W buffer), the
-    // lo.hi step re-uses the resident W hi tile and only A lo is fetched (other A buffer); the next K-tile's A hi / W hi go
-    // to the buffers that the hi.lo step has finished with. 4 tile fills per 3 MFMA passes instead of 6: this loop is bound
-    // by the global -> LDS fill rate (~48 GB/s per CU measured), so that is where the split modes' time goes.
+    // One step of the K loop multiplies an A tile by a W tile out of LDS while the DMA of later tiles is in flight; one
+    // __syncthreads per step drains that DMA and frees the buffers the step has read.
+    // Plain modes: step kt uses A / W buffers kt & 1 and prefetches K-tile kt + 1 into the other pair.
+    // Split modes with three terms: K-tile kt is three steps that SHARE their fills — 4 tile fills per 3 MFMA passes:
+    //     step   rows 0-63 of the tile (wave row 0)   rows 64-127 (wave row 1)   prefetched during the step
+    //     s1     A hi . W hi                          A hi . W lo                A lo (kt)      -> the other A buffer
+    //     s2     A hi . W lo                          A hi . W hi                W hi (kt + 1)  -> the free W buffer
+    //     s3     A lo . W hi                          A lo . W hi                A hi, W lo (kt + 1) -> the buffers s2 released
+    // (so W hi and W lo of a K-tile are both resident during s1 / s2: three W buffers). The two wave rows take hi.hi and
+    // hi.lo in opposite order ON PURPOSE: it is the order in which gemm256x3_kernel (gemm256.hip), whose phases are chained
+    // by register reuse, accumulates the first / second 64 rows of every 128-row block. launch_gemm16 splits a layer's rows
+    // between the two kernels by batch size; with the same order of fp32 additions per output element in both, an image's
+    // features do not depend on the batch it was encoded in (tests: ..._is_batch_invariant).
     const int nterm = SPLIT ? sp.terms : 1;
     auto issue_a = [&](size_t koff, int buf) {
-        char* ab = smem + buf * STG;
+        char* ab = smem + buf * ASZ;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + koff), (lds_void_t*)(ab + (wave * 4 + i) * 1024), 16, 0, 0);
     };
     auto issue_w = [&](size_t koff, int buf) {
-        char* wb = smem + buf * STG + BM * BK * 2;
+        char* wb = smem + 2 * ASZ + buf * WSZ;
 #pragma unroll
         for (int i = 0; i < WLD; ++i)
             __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[i] + koff), (lds_void_t*)(wb + (wave * WLD + i) * 1024), 16, 0, 0);
@@ -306,27 +314,28 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     const int nk = K / BK, nsteps = nk * nterm;
     issue_a(0, 0);
     issue_w(0, 0);
+    if (SPLIT && nterm == 3) issue_w(sp.w_lo, 1);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    int pa = 0, pw = 0;                    // buffers holding the current K-tile's A hi and W hi (three-term schedule)
+    int ih = 0, il = 1, ifree = 2;         // W buffers holding the current K-tile's W hi / W lo, and the free one (three-term schedule; A hi is always in A buffer 0, A lo in 1)
     for (int j = 0; j < nsteps; ++j) {
         int ia, iw;
-        if (nterm == 3) {
+        if (SPLIT && nterm == 3) {
             const int kt = j / 3, term = j - kt * 3;
             const size_t k0 = (size_t)kt * BK;
-            if (term == 0) { ia = pa; iw = pw; issue_w(k0 + sp.w_lo, pw ^ 1); }
-            else if (term == 1) { ia = pa; iw = pw ^ 1; issue_a(k0 + sp.a_lo, pa ^ 1); }
+            if (term == 0) { ia = 0; iw = wm ? il : ih; issue_a(k0 + sp.a_lo, 1); }
+            else if (term == 1) { ia = 0; iw = wm ? ih : il; if (kt + 1 < nk) issue_w(k0 + BK, ifree); }
             else {
-                ia = pa ^ 1; iw = pw;
-                if (kt + 1 < nk) { issue_a(k0 + BK, pa); issue_w(k0 + BK, pw ^ 1); }
-                pw ^= 1;                     // the next K-tile's W hi lands where this one's W lo was
+                ia = 1; iw = ih;
+                if (kt + 1 < nk) { issue_a(k0 + BK, 0); issue_w(k0 + BK + sp.w_lo, il); }
+                const int t = ih; ih = ifree; ifree = t;         // next K-tile: W hi is where s2 put it, the old W hi buffer is free
             }
         } else {
             ia = iw = j & 1;
             if (j + 1 < nsteps) { issue_a((size_t)(j + 1) * BK, ia ^ 1); issue_w((size_t)(j + 1) * BK, iw ^ 1); }
         }
-        const char* ab = smem + ia * STG;
-        const char* wb = smem + iw * STG + BM * BK * 2;
+        const char* ab = smem + ia * ASZ;
+        const char* wb = smem + 2 * ASZ + iw * WSZ;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             v8 af[4], wf[NT];
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<T>::mfma(wf[nt], af[mt], acc[nt][mt]);
         }
-        __syncthreads();   // drains the DMA of the next step's tiles (vmcnt(0)) and frees this step's buffers
+        __syncthreads();   // drains the DMA issued in this step (vmcnt(0)) and frees the buffers the step has read
     }
     if (SPLIT) gemm_epilogue_split<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg, sp);
     else gemm_epilogue<T, EPI, BN>(acc, smem, Cout, bias, resid, M, N, m0, n0, wm, wn, fr, fg);
