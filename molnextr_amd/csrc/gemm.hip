@@ -180,14 +180,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         a_ptr[i] = A + (size_t)ra * K + ld_c * 8;
         w_ptr[i] = W + (size_t)rw * K + ld_c * 8;
     }
-    // split modes: K-tile j of the loop is term j % 3 of K-tile j / 3: (A hi, W hi), (A hi, W lo), (A lo, W hi)
+    // split modes: K-tile j of the loop is term j % 3 of K-tile j / 3: (A hi, W lo), (A hi, W hi), (A lo, W hi) — the one
+    // order in which every encoder GEMM kernel accumulates the three terms (see gemm_tn_glds_kernel)
     const int nterm = SPLIT ? sp.terms : 1;
     const int nk = ((K + BK - 1) / BK) * nterm;
     Stage<T> st;
     auto load_g = [&](int j) {
-        const int kt = nterm == 3 ? j / 3 : j, term = nterm == 3 ? j - kt * 3 : 0;
+        const int kt = nterm == 3 ? j / 3 : j, term = nterm == 3 ? j - kt * 3 : 1;
         const int k0 = kt * BK;
-        const size_t ka = (size_t)k0 + (term == 2 ? sp.a_lo : 0), kw = (size_t)k0 + (term == 1 ? sp.w_lo : 0);
+        const size_t ka = (size_t)k0 + (term == 2 ? sp.a_lo : 0), kw = (size_t)k0 + (term == 0 ? sp.w_lo : 0);
         const bool ok = (k0 + ld_c * 8) < K;  // K % 8 == 0: a chunk is all-in or all-out
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -257,9 +258,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     constexpr int WLD = BN / 32;
     constexpr int ASZ = BM * BK * 2, WSZ = BN * BK * 2;        // one A tile (16 KiB), one W tile
     constexpr int EPI_LDS = 34816;    // largest epilogue staging area: 128 rows x (128 x 2 + 16) B = 128 x (64 x 4 + 16) B
-    // LDS: two A buffers, then two (plain modes) or three (split modes) W buffers
-    constexpr int NWB = SPLIT ? 3 : 2;
-    constexpr int RING = 2 * ASZ + NWB * WSZ;
+    constexpr int RING = 2 * ASZ + 2 * WSZ;                    // two A buffers, then two W buffers
     __shared__ __attribute__((aligned(16))) char smem[RING > EPI_LDS ? RING : EPI_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,15 +283,14 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     // __syncthreads per step drains that DMA and frees the buffers the step has read.
     // Plain modes: step kt uses A / W buffers kt & 1 and prefetches K-tile kt + 1 into the other pair.
     // Split modes with three terms: K-tile kt is three steps that SHARE their fills — 4 tile fills per 3 MFMA passes:
-    //     step   rows 0-63 of the tile (wave row 0)   rows 64-127 (wave row 1)   prefetched during the step
-    //     s1     A hi . W hi                          A hi . W lo                A lo (kt)      -> the other A buffer
-    //     s2     A hi . W lo                          A hi . W hi                W hi (kt + 1)  -> the free W buffer
-    //     s3     A lo . W hi                          A lo . W hi                A hi, W lo (kt + 1) -> the buffers s2 released
-    // (so W hi and W lo of a K-tile are both resident during s1 / s2: three W buffers). The two wave rows take hi.hi and
-    // hi.lo in opposite order ON PURPOSE: it is the order in which gemm256x3_kernel (gemm256.hip), whose phases are chained
-    // by register reuse, accumulates the first / second 64 rows of every 128-row block. launch_gemm16 splits a layer's rows
-    // between the two kernels by batch size; with the same order of fp32 additions per output element in both, an image's
-    // features do not depend on the batch it was encoded in (tests: ..._is_batch_invariant).
+    //     step   product        prefetched during the step
+    //     s1     A hi . W lo    W hi (kt)                -> the other W buffer
+    //     s2     A hi . W hi    A lo (kt)                -> the other A buffer
+    //     s3     A lo . W hi    A hi, W lo (kt + 1)      -> the buffers s1 / s2 released
+    // The term order hi.lo, hi.hi, lo.hi is the one in which gemm256x3_kernel (gemm256.hip), whose phases are chained by
+    // register reuse, can accumulate EVERY row; launch_gemm16 splits a layer's rows between the two kernels by batch size,
+    // and with the same order of fp32 additions per output element in both, an image's features do not depend on the
+    // batch it was encoded in (tests: ..._is_batch_invariant).
     const int nterm = SPLIT ? sp.terms : 1;
     auto issue_a = [&](size_t koff, int buf) {
         char* ab = smem + buf * ASZ;
@@ -312,23 +310,22 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = K / BK, nsteps = nk * nterm;
+    const bool three = SPLIT && nterm == 3;
     issue_a(0, 0);
-    issue_w(0, 0);
-    if (SPLIT && nterm == 3) issue_w(sp.w_lo, 1);
+    issue_w(three ? sp.w_lo : (size_t)0, 0);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    int ih = 0, il = 1, ifree = 2;         // W buffers holding the current K-tile's W hi / W lo, and the free one (three-term schedule; A hi is always in A buffer 0, A lo in 1)
+    int il = 0;                            // three-term schedule: W buffer holding the current K-tile's W lo (W hi: the other one; A hi is always in A buffer 0, A lo in 1)
     for (int j = 0; j < nsteps; ++j) {
         int ia, iw;
-        if (SPLIT && nterm == 3) {
+        if (three) {
             const int kt = j / 3, term = j - kt * 3;
             const size_t k0 = (size_t)kt * BK;
-            if (term == 0) { ia = 0; iw = wm ? il : ih; issue_a(k0 + sp.a_lo, 1); }
-            else if (term == 1) { ia = 0; iw = wm ? ih : il; if (kt + 1 < nk) issue_w(k0 + BK, ifree); }
+            if (term == 0) { ia = 0; iw = il; issue_w(k0, il ^ 1); }
+            else if (term == 1) { ia = 0; iw = il ^ 1; issue_a(k0 + sp.a_lo, 1); }
             else {
-                ia = 1; iw = ih;
+                ia = 1; iw = il ^ 1;
                 if (kt + 1 < nk) { issue_a(k0 + BK, 0); issue_w(k0 + BK + sp.w_lo, il); }
-                const int t = ih; ih = ifree; ifree = t;         // next K-tile: W hi is where s2 put it, the old W hi buffer is free
             }
         } else {
             ia = iw = j & 1;

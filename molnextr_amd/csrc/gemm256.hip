@@ -60,10 +60,9 @@ constexpr int P_STG = 2048;                        // per-wave staging patch: 16
 constexpr int P_LDS = 8 * SLOT + 8 * P_STG;        // 144 KiB
 constexpr int P_STORES = 16, P_BIAS = 4;           // VMEM operations per wave per tile besides the fills
 
-// SPLIT (kernels.h SplitArgs, dtypes BF16X3 / F16X3): the K-tile stream of a tile is 3 nk long — K-tile j is term j % 3 of
-// K-tile j / 3: (A hi, W hi), (A hi, W lo), (A lo, W hi), so the second read of a hi slab follows its first immediately
-// (L2 hit) — and the epilogue computes epi(oscale * acc + bias) with the exact-erf GELU and stores TWO planes (hi, lo):
-// 2 x P_STORES stores per wave per tile.
+// SPLIT (kernels.h SplitArgs, dtypes BF16X3 / F16X3) with terms == 1 (the error-budget aid): only the hi planes are
+// multiplied, the epilogue computes epi(oscale * acc + bias) with the exact-erf GELU and stores TWO planes (hi, lo):
+// 2 x P_STORES stores per wave per tile. All three terms: gemm256x3_kernel below.
 template <typename T, int EPI, bool SPLIT>
 __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W, T* __restrict__ C,
                                                        const float* __restrict__ bias, int M, int N, int K, int tiles_n,
@@ -77,12 +76,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
-    const int nterm = SPLIT ? sp.terms : 1;
-    const int nk = K / TK, nkk = nk * nterm;              // K-tiles per output tile: operand K-tiles x product terms
+    const int nk = K / TK, nkk = nk;
     const int my_first = blockIdx.x, stride = gridDim.x;
     const int my_tiles = (n_tiles - my_first + stride - 1) / stride;
     const int total_kt = my_tiles * nkk;                  // K-tiles this workgroup streams through the ring
-    const long a_lo_b = SPLIT ? (long)sp.a_lo * 2 : 0, w_lo_b = SPLIT ? (long)sp.w_lo * 2 : 0;
 
     // per-thread byte offsets of its two DMA pieces inside a tile (tile origin and K offset live in scalar registers)
     const int r_in = lane >> 3, pc = lane & 7;
@@ -98,7 +95,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
         }
     }
     // the fill stream's position: K-tile `f` (slots 0..2 are issued two K-tiles ahead, slot 3 one K-tile ahead)
-    struct Pos { const char* a; const char* w; int kt, seq, term; };
+    struct Pos { const char* a; const char* w; int kt, seq; };
     auto tile_origin = [&](int seq, int& m0, int& n0) {
         const int tile = xcd_remap(my_first + seq * stride, n_tiles);
         m0 = (tile / tiles_n) * TM; n0 = (tile % tiles_n) * TN;
@@ -106,15 +103,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
     auto pos_at = [&](int seq) {
         int m0, n0; tile_origin(seq, m0, n0);
         Pos q; q.a = (const char*)(A + (size_t)m0 * K); q.w = (const char*)(W + (size_t)n0 * K); q.kt = 0; q.seq = seq;
-        q.term = 0;
         return q;
     };
     auto advance = [&](Pos& q) {
-        if (SPLIT && nterm == 3) {
-            if (q.term == 0) { q.w += w_lo_b; q.term = 1; return; }                    // (A hi, W lo)
-            if (q.term == 1) { q.w -= w_lo_b; q.a += a_lo_b; q.term = 2; return; }     // (A lo, W hi)
-            q.a -= a_lo_b; q.term = 0;
-        }
         if (++q.kt == nk) { if (q.seq + 1 < my_tiles) q = pos_at(q.seq + 1); else { q.kt = 0; ++q.seq; } }
         else { q.a += TK * 2; q.w += TK * 2; }
     };
@@ -299,28 +290,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 // =====================================================================================================================
 // gemm256x3_kernel — the split-operand form with all three product terms (dtypes BF16X3 / F16X3, SplitArgs::terms == 3).
 //
-// gemm256_kernel<.., SPLIT> streams the three terms of a K-tile as three complete K-tiles: 12 slot fills and 72 fragment
-// reads per 192 MFMAs of a wave, although A hi and W hi are each needed twice. This kernel keeps the four operand slabs of
-// ONE K-tile resident — the 8 ring slots are A hi (2), A lo (2), W hi (2), W lo (2) — and walks the six 32-MFMA products
-// of the tile in an order in which consecutive products share one register operand:
+// Streaming the three terms of a K-tile as three complete K-tiles costs 12 slot fills and 72 fragment reads per 192 MFMAs
+// of a wave, although A hi and W hi are each needed twice. This kernel keeps the four operand slabs of ONE K-tile resident
+// — the 8 ring slots are A hi (2), A lo (2), W hi (2), W lo (2) — and walks the six 32-MFMA products of the tile in an
+// order in which consecutive products share one register operand:
 //
 //     phase  product      fragments read (LDS)            slot refilled at the START of the phase (read last in the
 //                                                          phase before)                       wait for (next phase)
-//     P1     Ah0 . Wh     Ah0 (8) + Wh (8)                A lo, rows 0-63   of THIS K-tile       W lo
-//     P2     Ah0 . Wl     Wl (8)   [Ah0 stays in regs]    A hi, rows 0-63   of the NEXT K-tile   Ah1
-//     P3     Ah1 . Wl     Ah1 (8)  [Wl stays]             W lo (both halves) of the next          —  (Wh landed before P1)
-//     P4     Ah1 . Wh     Wh (8)   [Ah1 stays]            A hi, rows 64-127 of the next          Al1
-//     P5     Al1 . Wh     Al1 (8)  [Wh stays]             W hi (both halves) of the next          Al0
-//     P6     Al0 . Wh     Al0 (8)  [Wh stays]             A lo, rows 64-127 of the next          Ah0', Wh' of the next
+//     P1     Ah0 . Wl     Ah0 (8) + Wl (8)                A lo, rows 64-127 of THIS K-tile       Ah1
+//     P2     Ah1 . Wl     Ah1 (8)  [Wl stays in regs]     W lo (both halves) of the NEXT K-tile   Wh
+//     P3     Ah1 . Wh     Wh (8)   [Ah1 stays]            A hi, rows 64-127 of the next          —  (Ah0 landed before P1)
+//     P4     Ah0 . Wh     Ah0 (8)  [Wh stays]             W hi (both halves) of the next          Al0
+//     P5     Al0 . Wh     Al0 (8)  [Wh stays]             A hi, rows 0-63   of the next          Al1
+//     P6     Al1 . Wh     Al1 (8)  [Wh stays]             A lo, rows 0-63   of the next          Ah0', Wl' of the next
 //
 // (rows = the first / second 64 rows of each wave-row block, as the Am0 / Am1 slots of gemm256_kernel; the W slots are its
-// Bn0 / Bn1.) 8 slot fills and 56 fragment reads per 192 MFMAs. Every slot is single-buffered: it is refilled in the phase
-// after its last read and needed again 5 phases later — except W hi (read in P1 and P4, refilled in P5, needed in P1: 2
-// phases), which is the operand that every M-tile of the launch shares and therefore always comes from L2.
+// Bn0 / Bn1.) 8 slot fills and 56 fragment reads per 192 MFMAs. EVERY output element accumulates its terms in the order
+// hi.lo, hi.hi, lo.hi within a K-tile — the order of the 128x128 kernel's three-term schedule (gemm.hip) — so that the two
+// kernels, between which launch_gemm16 splits a layer's rows by batch size, add the same fp32 numbers in the same order:
+// an image's features do not depend on the batch it is encoded in. (Chaining the phases by register reuse alone would
+// give the two row halves different orders — a uniform order costs one repeated fragment read, Ah0 in P1 and P4.)
+// Every slot is single-buffered: it is refilled in the phase after its last read and needed again 5 phases later —
+// except A hi rows 0-63 (read in P1 and P4, refilled in P5, needed in P1: 2 phases).
 // Phase skeleton, barrier pairing of the two wave rows (half a phase apart) and the epilogue are those of gemm256_kernel:
 // a slot read in phase n may be overwritten from the start of phase n + 1 (the other row passed its opening barrier of
 // phase n, after its reads); data read in phase n + 1 is waited for (counted vmcnt) before the opening barrier of phase n.
-// vmcnt: a wave issues 16 fill instructions per K-tile in the order P1: 2, P2: 2, P3: 4, P4: 2, P5: 4, P6: 2; the number
+// vmcnt: a wave issues 16 fill instructions per K-tile in the order P1: 2, P2: 4, P3: 2, P4: 4, P5: 2, P6: 2; the number
 // of younger operations allowed at each wait is derived below. First K-tile of the stream and last K-tile of the stream
 // (different in-flight population) drain instead of counting.
 // one 16-byte-per-lane LDS-DMA: LDS[lds + 16 lane] <- sbase[voff] (scalar base, 32-bit lane offset: no 64-bit VGPR address;
@@ -419,12 +414,12 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     tile_origin(0, m0, n0);
     load_bias(n0);
     Pos cur = pos_at(0);
-    // prologue: everything K-tile 0 needs except A lo rows 0-63 (issued by its own P1), in the order of first use
-    fill_a(cur.a, 0, S_AH0); fill_w(cur.w, S_WH0); fill_w(cur.w + w_lo_b, S_WL0); fill_a(cur.a, 1, S_AH1);
-    fill_a(cur.a + a_lo_b, 1, S_AL1);
+    // prologue: everything K-tile 0 needs except A lo rows 64-127 (issued by its own P1), in the order of first use
+    fill_a(cur.a, 0, S_AH0); fill_w(cur.w + w_lo_b, S_WL0); fill_a(cur.a, 1, S_AH1); fill_w(cur.w, S_WH0);
+    fill_a(cur.a + a_lo_b, 0, S_AL0);
     Pos nxt = cur;
     advance(nxt);
-    wait_vm<8>();                                 // bias, Ah0, Wh landed (W lo 4 + Ah1 2 + Al1 2 may fly)
+    wait_vm<8>();                                 // bias, Ah0, W lo landed (Ah1 2 + W hi 4 + Al0 2 may fly)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row starts one segment late
 
@@ -558,49 +553,49 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
         const bool has_next = g + 1 < total_kt;
         const bool first_kt = (kt == 0 && seq > 0);
         const bool drain = (g == 0) || !has_next;
-        // ---- P1: Ah0 . Wh -> rows 0..63.   refill: A lo rows 0-63 of THIS K-tile (its slot was read last in P6)
-        fill_a(cur.a + a_lo_b, 0, S_AL0);
+        // ---- P1: Ah0 . Wl -> rows 0..63.   refill: A lo rows 64-127 of THIS K-tile (its slot was read last in P6)
+        fill_a(cur.a + a_lo_b, 1, S_AL1);
         if (first_kt) load_bias(n0);
         read_a(R_AH0{});
-        read_w(R_WH{});
-        // W lo (issued in P3 of the previous K-tile). Younger: P4 2, P5 4, P6 2 [, PST stores], this phase's 2 [+ bias]
-        MNX_X3_WAIT(10, PST + X3_BIAS);
-        mfma_block(MB0{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P2: Ah0 . Wl -> rows 0..63.   refill: A hi rows 0-63 of the next K-tile
-        if (has_next) fill_a(nxt.a, 0, S_AH0);
         read_w(R_WL{});
-        // Ah1 (issued in P4 of the previous K-tile). Younger: P5 4, P6 2 [, PST stores], P1 2 [+ bias], P2 2
+        // Ah1 (issued in P3 of the previous K-tile). Younger: P4 4, P5 2, P6 2 [, PST stores], this phase's 2 [+ bias]
         MNX_X3_WAIT(10, PST + X3_BIAS);
         mfma_block(MB0{});
         __builtin_amdgcn_s_barrier();
-        // ---- P3: Ah1 . Wl -> rows 64..127.   refill: W lo of the next K-tile.   P4 re-reads W hi: landed before P1
+        // ---- P2: Ah1 . Wl -> rows 64..127.   refill: W lo of the next K-tile
         if (has_next) fill_w(nxt.w + w_lo_b, S_WL0);
         read_a(R_AH1{});
+        // W hi (issued in P4 of the previous K-tile). Younger: P5 2, P6 2 [, PST stores], P1 2 [+ bias], P2 4
+        MNX_X3_WAIT(10, PST + X3_BIAS);
+        mfma_block(MB4{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P3: Ah1 . Wh -> rows 64..127.   refill: A hi rows 64-127 of the next K-tile.   P4 re-reads Ah0: landed before P1
+        if (has_next) fill_a(nxt.a, 1, S_AH1);
+        read_w(R_WH{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         mfma_block(MB4{});
         __builtin_amdgcn_s_barrier();
-        // ---- P4: Ah1 . Wh -> rows 64..127.   refill: A hi rows 64-127 of the next K-tile
-        if (has_next) fill_a(nxt.a, 1, S_AH1);
-        read_w(R_WH{});
-        // Al1 (issued in P6 of the previous K-tile, before its epilogue). Younger: [PST stores,] P1 2 [+ bias], P2 2, P3 4, P4 2
-        MNX_X3_WAIT(10, PST + X3_BIAS);
-        mfma_block(MB4{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P5: Al1 . Wh -> rows 64..127.   refill: W hi of the next K-tile
+        // ---- P4: Ah0 . Wh -> rows 0..63.   refill: W hi of the next K-tile (its fragments stay in registers until P6)
         if (has_next) fill_w(nxt.w, S_WH0);
-        read_a(R_AL1{});
-        // Al0 (issued in P1 of this K-tile, before the bias loads). Younger: [bias,] P2 2, P3 4, P4 2, P5 4
-        MNX_X3_WAIT(12, X3_BIAS);
-        mfma_block(MB4{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P6: Al0 . Wh -> rows 0..63.   refill: A lo rows 64-127 of the next K-tile
-        if (has_next) fill_a(nxt.a + a_lo_b, 1, S_AL1);
-        read_a(R_AL0{});
-        // Ah0', Wh' of the next K-tile (issued in P2 / P5). Younger than Wh': this phase's 2
-        MNX_X3_WAIT(2, 0);
+        read_a(R_AH0{});
+        // Al0 (issued in P6 of the previous K-tile, before its epilogue). Younger: [PST stores,] P1 2 [+ bias], P2 4, P3 2, P4 4
+        MNX_X3_WAIT(12, PST + X3_BIAS);
         mfma_block(MB0{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P5: Al0 . Wh -> rows 0..63.   refill: A hi rows 0-63 of the next K-tile
+        if (has_next) fill_a(nxt.a, 0, S_AH0);
+        read_a(R_AL0{});
+        // Al1 (issued in P1 of this K-tile, before the bias DMA). Younger: [bias,] P2 4, P3 2, P4 4, P5 2
+        MNX_X3_WAIT(12, X3_BIAS);
+        mfma_block(MB0{});
+        __builtin_amdgcn_s_barrier();
+        // ---- P6: Al1 . Wh -> rows 64..127.   refill: A lo rows 0-63 of the next K-tile
+        if (has_next) fill_a(nxt.a + a_lo_b, 0, S_AL0);
+        read_a(R_AL1{});
+        // Ah0', Wl' of the next K-tile (issued in P5 / P2). Younger than Ah0': this phase's 2
+        MNX_X3_WAIT(2, 0);
+        mfma_block(MB4{});
         // epilogue placement as gemm256_kernel: second wave row before its closing barrier, first row after its own
         if (last_kt && wr == 1) epilogue();
         __builtin_amdgcn_s_barrier();
@@ -697,6 +692,8 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
     const bool split = dt_split(dtype);
     if (split && (!sp || (sp->terms != 1 && sp->terms != 3))) return hipErrorInvalidValue;
     const SplitArgs spv = split ? *sp : SplitArgs();
+    if (split && spv.terms == 3)        // all three terms: the shared-fill six-phase kernel
+        return launch_gemm256x3(dtype, epi, A, W, C, bias, nullptr, M, N, K, s, sp);
     const int tm = M / TM, tn = N / TN;
     const int grid = tm * tn < 256 ? tm * tn : 256;
 #define MNX_G256_CASE(TT, E, SP)                                                                                          \
@@ -709,8 +706,6 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
     }
 #define MNX_G256_TYPE(TT, SP)                                                                                             \
     switch (epi) { MNX_G256_CASE(TT, EPI_BIAS_16, SP) MNX_G256_CASE(TT, EPI_GELU_16, SP) default: return hipErrorInvalidValue; }
-    if (split && spv.terms == 3)        // all three terms: the shared-fill six-phase kernel
-        return launch_gemm256x3(dtype, epi, A, W, C, bias, nullptr, M, N, K, s, sp);
     if (dtype == MNX_DT_F16) { MNX_G256_TYPE(f16_t, false) }
     else if (dtype == MNX_DT_BF16) { MNX_G256_TYPE(bf16_t, false) }
     else if (dtype == MNX_DT_F16X3) { MNX_G256_TYPE(f16_t, true) }

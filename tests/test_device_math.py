@@ -91,11 +91,12 @@ def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
         if out16:
             # one copy of the K-tile body: prologue 15 DMAs + 1 bias in P1 + 16 per K-tile; no compiler-made wait
             assert n_dma == 32, (name, n_dma)
-            assert waits == [0, 0, 0, 0, 0, 2, 2, 8, 10, 10, 10, 12, 13, 43, 43, 43], (name, waits)
+            assert waits == [0, 0, 0, 0, 0, 2, 2, 8, 10, 10, 12, 12, 13, 43, 43, 45], (name, waits)
             assert len(re.findall(r"s_barrier", body)) == 15, name
         else:
             # fp32 epilogues use ordinary loads / stores: the compiler adds its own (stricter) waits inside the epilogue and
             # may duplicate the K-tile body; the counted waits of the phases must all be there
-            first = 63 if "Li2E" in name else 43
-            for w, n in ((10, 3), (12, 1), (13, 1), (8, 1), (first, 3)):
+            expect = {10: 2, 12: 2, 13: 1, 8: 1}
+            expect.update({63: 3} if "Li2E" in name else {43: 2, 45: 1})
+            for w, n in expect.items():
                 assert waits.count(w) >= n and waits.count(w) % n == 0, (name, w, waits.count(w))
