@@ -7,14 +7,19 @@ cannot be installed, so nothing below can be executed or tested here. Behaviour:
     bonds and the decoder's raw token SMILES; BASELINE's "SMILES exact-match" is therefore checkable on the raw token
     SMILES + atom / bond sets only — every result that reports a match says so (evaluate.smiles_scores);
   * with RDKit: the molecule graph is built exactly as `_convert_graph_to_smiles` builds it (chemical.py:880-925:
-    `Chem.AtomFromSmiles(symbol)` so charges / isotopes / explicit H survive, chiral tag cleared, '*' + alias for
-    R-groups / abbreviations / unparsable symbols, BondDir BEGINWEDGE / BEGINDASH for bond classes 5 / 6). The
+    the de-bracketed symbol is looked up in the R-group and abbreviation tables FIRST (:886-898 — 'Ac', 'Ts', 'Pr', 'Ar',
+    'Y' ... are shorthand there, not actinium / tennessine / praseodymium / argon / yttrium; the tables are data,
+    vocab/abbreviations.json), then `Chem.AtomFromSmiles(symbol)` so charges / isotopes / explicit H survive, chiral tag
+    cleared, '*' + alias for R-groups / abbreviations / unparsable symbols, BondDir BEGINWEDGE / BEGINDASH for bond
+    classes 5 / 6). The
     reference then runs `_verify_chirality` (:212-287) and `_expand_functional_group` (:565-877), ~400 lines of RDKit
     calls that are NOT restated (they cannot be validated here). A molecule that needs either — it has a wedge bond
     or an alias atom — is reported as failed (`None`, success False) instead of a plausible but different SMILES;
     only molecules that need neither get a SMILES.
 """
+import json
 import logging
+import os
 from typing import List, Tuple
 
 import numpy as np
@@ -34,6 +39,23 @@ def have_rdkit() -> bool:
     return _HAVE_RDKIT
 
 
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "vocab", "abbreviations.json")) as _f:
+    _tables = json.load(_f)
+RGROUP_SYMBOLS = frozenset(_tables["rgroup_symbols"])       # reference abbrs.py:8-10
+ABBREVIATIONS = frozenset(_tables["abbreviations"])         # keys of the reference's ABBREVIATIONS (abbrs.py:218)
+
+
+def classify_symbol(symbol: str) -> str:
+    """'rgroup' | 'abbreviation' | 'atom' for one atom token, in the reference's order of tests (chemical.py:886-898):
+    brackets stripped, R-group table, abbreviation table, and only then a chemical element / SMILES atom."""
+    inner = symbol[1:-1] if symbol[:1] == "[" and symbol[-1:] == "]" else symbol
+    if inner in RGROUP_SYMBOLS:
+        return "rgroup"
+    if inner in ABBREVIATIONS:
+        return "abbreviation"
+    return "atom"
+
+
 def _graph_to_smiles(coords, symbols, edges) -> Tuple[object, object, bool]:  # pragma: no cover - needs RDKit
     mol = Chem.RWMol()
     n = len(symbols)
@@ -41,12 +63,13 @@ def _graph_to_smiles(coords, symbols, edges) -> Tuple[object, object, bool]:  # 
     for i, sym in enumerate(symbols):
         inner = sym[1:-1] if sym[0] == "[" else sym
         atom = None
-        try:
-            atom = Chem.AtomFromSmiles(sym)
-            if atom is not None:
-                atom.SetChiralTag(Chem.rdchem.ChiralType.CHI_UNSPECIFIED)
-        except Exception:  # noqa: BLE001
-            atom = None
+        if classify_symbol(sym) == "atom":               # shorthand is never handed to AtomFromSmiles (it would parse)
+            try:
+                atom = Chem.AtomFromSmiles(sym)
+                if atom is not None:
+                    atom.SetChiralTag(Chem.rdchem.ChiralType.CHI_UNSPECIFIED)
+            except Exception:  # noqa: BLE001
+                atom = None
         if atom is None or atom.GetSymbol() == "*":      # R-group, abbreviation or condensed formula
             atom = Chem.Atom("*")
             if inner[:1] == "R" and inner[1:].isdigit():

@@ -161,6 +161,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
     int kt = 0, seq = 0;
     auto epilogue = [&]() {
         // ---- epilogue of tile `seq`: 16-row slabs of the wave tile through the wave's own staging patch ----
+        // b4 was written by untracked loads at the tile's first K-tile; every counted wait since then has retired them (they
+        // are older than the fills those waits cover). The empty asm is the point from which the compiler may read b4: it
+        // cannot hoist, copy or rematerialise a use above it.
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(b4[nt]));
         T* crow = C + (size_t)(m0 + wr * 128 + (lane >> 3)) * N + n0 + wc * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
