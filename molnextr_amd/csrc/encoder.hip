@@ -272,6 +272,7 @@ __global__ __launch_bounds__(576) void window_attn_kernel(const T* __restrict__ 
     __shared__ __attribute__((aligned(16))) T Ks[WN * KS_STRIDE];
     __shared__ __attribute__((aligned(16))) T Vt[HD * VT_STRIDE];
     __shared__ float tab[(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int rowof[WN];
     __shared__ __attribute__((aligned(16))) int kinfo[WN];   // per key: (ky*23 + kx) | region id << 16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,20 +284,26 @@ __global__ __launch_bounds__(576) void window_attn_kernel(const T* __restrict__ 
     const int wx = bid % nWw; bid /= nWw;
     const int wy = bid % nWh;
     const int b = bid / nWh;
-    // token t of the (shifted) window -> its row in the un-shifted [B*H*W] token order. Pure arithmetic: the K / V / q
-    // loads below depend on nothing that another thread computes, so they are issued at once and the table / key-info
-    // set-up shares their latency and the single barrier in front of the matrix instructions.
-    auto row_of = [&](int t) {
-        const int ty = t / WS, tx = t - ty * WS;
-        int yo = wy * WS + ty + shift; if (yo >= H) yo -= H;
-        int xo = wx * WS + tx + shift; if (xo >= W) xo -= W;
-        return (b * H + yo) * W + xo;
-    };
+
+    const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
+    for (int t = tid; t < WN; t += NTHR) {
+        const int ty = t / WS, tx = t % WS;
+        int ys = wy * WS + ty, xs = wx * WS + tx;
+        int yo = ys + shift; if (yo >= H) yo -= H;
+        int xo = xs + shift; if (xo >= W) xo -= W;
+        rowof[t] = (b * H + yo) * W + xo;
+        const int reg = (last_y ? (ty < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (tx < WS - shift ? 1 : 2) : 0);
+        kinfo[t] = (ty * (2 * WS - 1) + tx) | (reg << 16);
+    }
+    for (int i = tid; i < 529; i += NTHR) tab[i] = table[i * heads + head];
+    for (int i = tid; i < HD * (VT_STRIDE - WN); i += NTHR)
+        Vt[(i / (VT_STRIDE - WN)) * VT_STRIDE + WN + i % (VT_STRIDE - WN)] = (T)0.f;
+    __syncthreads();
 
     const size_t ld = (size_t)3 * C;
     for (int i = tid; i < WN * 4; i += NTHR) {       // 576 16-byte chunks each for K and V
         const int key = i >> 2, g8 = i & 3;
-        const T* base = qkv + (size_t)row_of(key) * ld + head * HD + g8 * 8;
+        const T* base = qkv + (size_t)rowof[key] * ld + head * HD + g8 * 8;
         const v8 kv = *(const v8*)(base + C);
         const v8 vv = *(const v8*)(base + 2 * C);
         *(v8*)(Ks + key * KS_STRIDE + g8 * 8) = kv;
@@ -308,18 +315,9 @@ __global__ __launch_bounds__(576) void window_attn_kernel(const T* __restrict__ 
     int qrow[QT];
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
-        qrow[q] = row_of((wave * QT + q) * 16 + fr);
+        qrow[q] = rowof[(wave * QT + q) * 16 + fr];
         qf[q] = *(const v8*)(qkv + (size_t)qrow[q] * ld + head * HD + fg * 8);
     }
-    const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
-    for (int t = tid; t < WN; t += NTHR) {
-        const int ty = t / WS, tx = t % WS;
-        const int reg = (last_y ? (ty < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (tx < WS - shift ? 1 : 2) : 0);
-        kinfo[t] = (ty * (2 * WS - 1) + tx) | (reg << 16);
-    }
-    for (int i = tid; i < 529; i += NTHR) tab[i] = table[i * heads + head];
-    for (int i = tid; i < HD * (VT_STRIDE - WN); i += NTHR)
-        Vt[(i / (VT_STRIDE - WN)) * VT_STRIDE + WN + i % (VT_STRIDE - WN)] = (T)0.f;
     __syncthreads();
 
     // ---- S^T[key][query] -------------------------------------------------------------------
@@ -417,6 +415,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
     __shared__ __attribute__((aligned(16))) T Ks[2][WN * KS_STRIDE];
     __shared__ __attribute__((aligned(16))) T Vt[2][HD * VT_STRIDE];
     __shared__ float tab[(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int rowof[WN];
     __shared__ __attribute__((aligned(16))) int kinfo[WN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,30 +425,14 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
     const int wx = bid % nWw; bid /= nWw;
     const int wy = bid % nWh;
     const int b = bid / nWh;
-    auto row_of = [&](int t) {       // as window_attn_kernel: no thread waits for another before its loads are in flight
-        const int ty = t / WS, tx = t - ty * WS;
-        int yo = wy * WS + ty + shift; if (yo >= H) yo -= H;
-        int xo = wx * WS + tx + shift; if (xo >= W) xo -= W;
-        return (b * H + yo) * W + xo;
-    };
 
-    const size_t ld = (size_t)3 * C;
-    for (int i = tid; i < 2 * WN * 4; i += NTHR) {       // 576 16-byte chunks each for K and V, two planes
-        const int pl = i / (WN * 4), key = (i >> 2) % WN, g8 = i & 3;
-        const T* base = qkv + (pl ? qkv_lo : (size_t)0) + (size_t)row_of(key) * ld + head * HD + g8 * 8;
-        const v8 kv = *(const v8*)(base + C);
-        const v8 vv = *(const v8*)(base + 2 * C);
-        *(v8*)(Ks[pl] + key * KS_STRIDE + g8 * 8) = kv;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[pl][(g8 * 8 + j) * VT_STRIDE + key] = vv[j];
-    }
-    const int fr = lane & 15, fg = lane >> 4;
-    const int qrow = row_of(wave * 16 + fr);
-    const v8 qh = *(const v8*)(qkv + (size_t)qrow * ld + head * HD + fg * 8);
-    const v8 ql = *(const v8*)(qkv + qkv_lo + (size_t)qrow * ld + head * HD + fg * 8);
     const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
     for (int t = tid; t < WN; t += NTHR) {
         const int ty = t / WS, tx = t % WS;
+        int ys = wy * WS + ty, xs = wx * WS + tx;
+        int yo = ys + shift; if (yo >= H) yo -= H;
+        int xo = xs + shift; if (xo >= W) xo -= W;
+        rowof[t] = (b * H + yo) * W + xo;
         const int reg = (last_y ? (ty < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (tx < WS - shift ? 1 : 2) : 0);
         kinfo[t] = (ty * (2 * WS - 1) + tx) | (reg << 16);
     }
@@ -458,6 +441,22 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
         const int pl = i / (HD * (VT_STRIDE - WN)), j = i % (HD * (VT_STRIDE - WN));
         Vt[pl][(j / (VT_STRIDE - WN)) * VT_STRIDE + WN + j % (VT_STRIDE - WN)] = (T)0.f;
     }
+    __syncthreads();
+
+    const size_t ld = (size_t)3 * C;
+    for (int i = tid; i < 2 * WN * 4; i += NTHR) {       // 576 16-byte chunks each for K and V, two planes
+        const int pl = i / (WN * 4), key = (i >> 2) % WN, g8 = i & 3;
+        const T* base = qkv + (pl ? qkv_lo : (size_t)0) + (size_t)rowof[key] * ld + head * HD + g8 * 8;
+        const v8 kv = *(const v8*)(base + C);
+        const v8 vv = *(const v8*)(base + 2 * C);
+        *(v8*)(Ks[pl] + key * KS_STRIDE + g8 * 8) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[pl][(g8 * 8 + j) * VT_STRIDE + key] = vv[j];
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qrow = rowof[wave * 16 + fr];
+    const v8 qh = *(const v8*)(qkv + (size_t)qrow * ld + head * HD + fg * 8);
+    const v8 ql = *(const v8*)(qkv + qkv_lo + (size_t)qrow * ld + head * HD + fg * 8);
     __syncthreads();
 
     const bool x3 = terms == 3;
