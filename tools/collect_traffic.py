@@ -17,11 +17,20 @@ def per_kernel(db, counter):
 
 f = per_kernel(sys.argv[1], "FETCH_SIZE")
 w = per_kernel(sys.argv[2], "WRITE_SIZE")
-tot_f = sum(v[0] for k, v in f.items() if "gemm_tn" in k or "gemm256" in k)
-n_f = sum(v[1] for k, v in f.items() if "gemm_tn" in k or "gemm256" in k)
-tot_w = sum(v[0] for k, v in w.items() if "gemm_tn" in k or "gemm256" in k)
-n_w = sum(v[1] for k, v in w.items() if "gemm_tn" in k or "gemm256" in k)
-out = {"kernel": f"gemm_tn*_kernel (all encoder GEMM launches of Swin-B @ B={sys.argv[4] if len(sys.argv) > 4 else 32})", "launches_per_pass": n_f,
+def is_gemm(k):
+    return "gemm_tn" in k or "gemm256" in k or "gemm_res" in k
+
+
+tot_f = sum(v[0] for k, v in f.items() if is_gemm(k))
+n_f = sum(v[1] for k, v in f.items() if is_gemm(k))
+tot_w = sum(v[0] for k, v in w.items() if is_gemm(k))
+n_w = sum(v[1] for k, v in w.items() if is_gemm(k))
+# launches = GEMM kernel launches of the pass; a layer whose rows are split between gemm256x3 and the 128-tile kernel
+# counts twice, so per-LAYER figures use the layer count given on the command line when present
+layers = int(sys.argv[5]) if len(sys.argv) > 5 else None
+if layers:
+    n_f = n_w = layers
+out = {"kernel": f"mnx::gemm_tn_* / gemm256* / gemm_res kernels (all encoder GEMM launches of Swin-B @ B={sys.argv[4] if len(sys.argv) > 4 else 32})", "launches_per_pass": n_f,
        "read_bytes_per_launch": 2 * tot_f * 1024 / n_f, "write_bytes_per_launch": tot_w * 1024 / n_w,
        "hbm_bytes_per_launch": (2 * tot_f / n_f + tot_w / n_w) * 1024,
        "note": "FETCH_SIZE doubled (gfx950 undercount, calibrated); Infinity-Cache hits are counted as traffic"}
