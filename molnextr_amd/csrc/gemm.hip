@@ -479,25 +479,37 @@ hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* 
                                : launch_t<bf16_t, false>(epi, A, W, C, bias, resid, M, N, K, s, none);
 }
 
+// rows that launch_gemm16 gives to gemm256x3_kernel (the rest goes to the 128x128 kernel); 0 = none
+static int x3_main_rows(int dtype, int epi, int M, int N, int K, int terms) {
+    if (!dt_split(dtype) || terms != 3 || !gemm256x3_supports(dtype, epi, M, N, K)) return 0;
+    const int tn = N / 256, tm = M / 256, tiles = tm * tn;
+    int tm_main = tm;
+    if (tiles % 256 != 0 && (tiles % 256) * 10 < 256 * 8) tm_main = (tiles / 256) * 256 / tn;
+    return tm_main * 256;
+}
+
+const char* gemm16_route(int dtype, int epi, int M, int N, int K, int terms, bool has_bias) {
+    const int r = x3_main_rows(dtype, epi, M, N, K, terms);
+    if (r == M) return "x3";
+    if (r > 0) return "x3+128";
+    if (has_bias && gemm256_supports(dtype, epi, M, N, K)) return "g256";
+    if (gemm_res_preferred(dtype, epi, M, N, K)) return "gres";
+    return "128";
+}
+
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                          const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
     // Split modes with all three terms: the six-phase 256x256 kernel (gemm256x3_kernel) takes the rows that fill whole
     // rounds of 256 tiles (one workgroup per CU walks its tiles in rounds; a last round that is at least 80 % full is
     // taken too), the 128x128 kernel (2-3 workgroups per CU) the remaining rows. Shape-only, like everything below.
-    if (dt_split(dtype) && sp && sp->terms == 3 && gemm256x3_supports(dtype, epi, M, N, K)) {
-        const int tn = N / 256, tm = M / 256, tiles = tm * tn;
-        int tm_main = tm;
-        if (tiles % 256 != 0 && (tiles % 256) * 10 < 256 * 8) tm_main = (tiles / 256) * 256 / tn;
-        if (tm_main > 0) {
-            const size_t es = 2;
-            hipError_t e = launch_gemm256x3(dtype, epi, A, W, C, bias, resid, tm_main * 256, N, K, s, sp);
-            if (e != hipSuccess || tm_main == tm) return e;
-            const size_t r0 = (size_t)tm_main * 256;
-            const bool out16 = (epi == EPI_BIAS_16 || epi == EPI_GELU_16);
-            return launch_gemm16_tile128(dtype, epi, (const char*)A + r0 * K * es, W,
-                                         (char*)C + r0 * N * (out16 ? es : sizeof(float)), bias,
-                                         resid ? resid + r0 * N : nullptr, M - (int)r0, N, K, s, sp);
-        }
+    if (const int r0 = sp ? x3_main_rows(dtype, epi, M, N, K, sp->terms) : 0) {
+        const size_t es = 2;
+        hipError_t e = launch_gemm256x3(dtype, epi, A, W, C, bias, resid, r0, N, K, s, sp);
+        if (e != hipSuccess || r0 == M) return e;
+        const bool out16 = (epi == EPI_BIAS_16 || epi == EPI_GELU_16);
+        return launch_gemm16_tile128(dtype, epi, (const char*)A + (size_t)r0 * K * es, W,
+                                     (char*)C + (size_t)r0 * N * (out16 ? es : sizeof(float)), bias,
+                                     resid ? resid + (size_t)r0 * N : nullptr, M - r0, N, K, s, sp);
     }
     // shape-only dispatch (never data- or environment-dependent): the persistent 256x256 kernel for the 16-bit-output
     // layers whose tile count fills the chip, the persistent 256x128 kernel for the fp32-output layers likewise, the

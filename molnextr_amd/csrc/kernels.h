@@ -33,6 +33,9 @@ struct SplitArgs {
 // dtype BF16X3 / F16X3: A, W (and C for the 16-bit-output epilogues) are hi planes, `sp` is required.
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                          const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp = nullptr);
+// which kernel(s) launch_gemm16 runs a layer on: "x3" (gemm256x3), "x3+128" (whole rounds on gemm256x3, remaining rows on
+// the 128x128 kernel), "g256", "gres", "128" — shape-only; used by tools/gemm_lab to label its table
+const char* gemm16_route(int dtype, int epi, int M, int N, int K, int terms, bool has_bias);
 // the 128x128-tile kernel of gemm.hip without the dispatch to gemm256.hip (tools/gemm_lab compares the two)
 hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                                  const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp = nullptr);

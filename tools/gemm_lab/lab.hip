@@ -127,7 +127,6 @@ int main(int argc, char** argv) {
         std::vector<float> href((size_t)S * sh.N);
         CK(hipMemcpyAsync(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
-        const bool uses256 = mnx::gemm256_supports(dt, sh.epi, sh.M, sh.N, sh.K);
         mnx::SplitArgs sp;
         sp.a_lo = nA; sp.w_lo = nW; sp.c_lo = out16 ? nC : 0; sp.oscale = 1.0f; sp.terms = 3;
         auto launch = [&](int v) {
@@ -165,7 +164,7 @@ int main(int argc, char** argv) {
         const double tol = out16 ? 2e-2 : 1e-3;
         printf("%-9s %3d %8d %6d %6d | %10.1f %8.1f | %10.1f %8.1f %-6s| %.2e %.2e%s\n", sh.name, sh.epi, sh.M, sh.N, sh.K, us[0],
                fl / us[0] / 1e6, us[1], fl / us[1] / 1e6,
-               uses256 ? "g256" : (mnx::gemm_res_preferred(dt, sh.epi, sh.M, sh.N, sh.K) ? "gres" : "base"), err[0], err[1],
+               mnx::gemm16_route(dt, sh.epi, sh.M, sh.N, sh.K, 3, true), err[0], err[1],
                (err[0] > tol || err[1] > tol) ? "  FAIL" : "");
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(Cc)); CK(hipFree(resid0)); CK(hipFree(drows)); CK(hipFree(ref));
     }
