@@ -1053,13 +1053,7 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         // ---- encoder prefetch: keep both feature buffers busy on the encoder stream
         for (int fb = 0; fb < 2; ++fb) {
             if (fb_first[fb] >= 0 || next_enc >= n_chunks) continue;
-            // Launch-group size: full groups while more than one group's worth of reference batches remains, then HALVING
-            // groups (rem/2, rem/4, ... 1). A job ends when the longest sequence of the batch admitted last has been
-            // decoded — one dependent tick per token after its admission — so the final admission should carry few
-            // sequences (their longest is shorter than the longest of a full group) and the batches before it should
-            // get a head start; the smaller groups cost a few % of encoder efficiency on the last group only.
-            const int rem = n_chunks - next_enc;
-            const int cnt = rem > grp ? grp : std::max(1, (rem + 1) / 2);
+            const int cnt = std::min(grp, n_chunks - next_enc);
             const int first = next_enc * ref_batch, n = std::min(cnt * ref_batch, n_img - first);
             if (feat_used[fb]) HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_feat_free[fb], 0));
             rc = mnx_encode(h, images + (size_t)first * img_elems, n, h->feat_ring[fb], h->enc_stream);
