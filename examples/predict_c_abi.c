@@ -19,7 +19,7 @@ int run(const mnx_weight_desc* weights, int n_weights, const float* host_images 
     { const int d[4] = {2, 2, 18, 2}, h[4] = {4, 8, 16, 32}; memcpy(cfg.depths, d, sizeof d); memcpy(cfg.heads, h, sizeof h); }
     cfg.dec_layers = 6; cfg.dec_dim = 256; cfg.dec_heads = 8; cfg.dec_ff = 1024;
     cfg.vocab = 229; cfg.sym_offset = 101; cfg.coord_bins = 64; cfg.pe_len = 5000;
-    cfg.max_len = 480; cfg.max_batch = 64; cfg.max_atoms = 160; cfg.compute_dtype = MNX_DTYPE_BF16; cfg.dec_slots = 3072;
+    cfg.max_len = 480; cfg.max_batch = 64; cfg.max_atoms = 160; cfg.compute_dtype = MNX_DTYPE_FP16X3; cfg.dec_slots = 3072;
 
     mnx_engine* eng = NULL;
     if (mnx_create(&cfg, weights, n_weights, /*device=*/0, &eng) != MNX_OK) {

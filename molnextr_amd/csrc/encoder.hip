@@ -11,74 +11,79 @@ namespace mnx {
 
 // =============================================================================================
 // K1  patch embedding: Conv2d(3, C, k=4, s=4) + bias -> LayerNorm(C)     (reference transformers.py:405-419)
-//     One workgroup = 32 consecutive patches of one patch-row; one wave normalises one patch at a time
-//     (lane owns channels lane and lane+64), so the LayerNorm reduction is a wavefront reduction.
+//     One workgroup = one patch row of one image (chunks of 32 patches, 8 threads per patch).
 // =============================================================================================
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w_t,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ x,
                                                           int S, int C, int G) {
-    // 32 patches per workgroup; 8 threads per patch, each owning CPT = C/8 consecutive channels (<= 16), so the
-    // LayerNorm reduction is 3 cross-lane steps and every patch row is written as one contiguous C*4-byte run.
+    // One workgroup = one patch ROW of one image, walked in chunks of 32 patches: the [48][C] weight image (24 KiB at
+    // C = 128, more than the 16 KiB of tokens a chunk produces) is staged in LDS once per row, not once per chunk.
+    // 8 threads per patch, each owning CPT = C/8 consecutive channels (<= 16), so the LayerNorm reduction is 3
+    // cross-lane steps and every patch row is written as one contiguous C*4-byte run.
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wt = sm;             // [48][C]
     float* pix = sm + 48 * C;   // [3][4][128]
     const int tid = threadIdx.x;
-    const int px0 = blockIdx.x * 32, py = blockIdx.y, b = blockIdx.z;
+    const int py = blockIdx.x, b = blockIdx.y;
     for (int i = tid; i < 48 * C; i += 256) wt[i] = w_t[i];
-    for (int i = tid; i < 3 * 4 * 128; i += 256) {
-        int ci = i >> 9, ky = (i >> 7) & 3, xx = i & 127;
-        int gx = px0 * 4 + xx;
-        pix[i] = gx < S ? img[((size_t)(b * 3 + ci) * S + (py * 4 + ky)) * S + gx] : 0.f;
-    }
-    __syncthreads();
     const int p = tid >> 3, part = tid & 7;
-    const int px = px0 + p;
     const int cpt = C >> 3;                 // channels per thread: 4, 8, 12 or 16
     const int c0 = part * cpt;
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = j < cpt ? bias[c0 + j] : 0.f;
-#pragma unroll 4
-    for (int i = 0; i < 48; ++i) {
-        const float v = pix[((i >> 2) << 7) + p * 4 + (i & 3)];  // (ci*4+ky)*128 + p*4 + kx
-        const float* wr = wt + i * C + c0;
-#pragma unroll
-        for (int j = 0; j < 16; j += 4)
-            if (j < cpt) {
-                const f32x4 w4 = *(const f32x4*)(wr + j);
-                acc[j] = fmaf(v, w4[0], acc[j]); acc[j + 1] = fmaf(v, w4[1], acc[j + 1]);
-                acc[j + 2] = fmaf(v, w4[2], acc[j + 2]); acc[j + 3] = fmaf(v, w4[3], acc[j + 3]);
-            }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s += j < cpt ? acc[j] : 0.f;
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    const float mean = s / (float)C;
-    float sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (j < cpt) { acc[j] -= mean; sq += acc[j] * acc[j]; }
-    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-    const float rstd = rsqrtf(sq / (float)C + 1e-5f);
-    if (px >= G) return;
-    float* o = x + ((size_t)(b * G + py) * G + px) * C + c0;
-#pragma unroll
-    for (int j = 0; j < 16; j += 4)
-        if (j < cpt) {
-            const f32x4 g4 = *(const f32x4*)(gamma + c0 + j), b4 = *(const f32x4*)(beta + c0 + j);
-            f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
-            *(f32x4*)(o + j) = v * rstd * g4 + b4;
+    for (int px0 = 0; px0 < G; px0 += 32) {
+        if (px0 > 0) __syncthreads();       // the previous chunk's pixels have been consumed
+        for (int i = tid; i < 3 * 4 * 128; i += 256) {
+            int ci = i >> 9, ky = (i >> 7) & 3, xx = i & 127;
+            int gx = px0 * 4 + xx;
+            pix[i] = gx < S ? img[((size_t)(b * 3 + ci) * S + (py * 4 + ky)) * S + gx] : 0.f;
         }
+        __syncthreads();
+        const int px = px0 + p;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = j < cpt ? bias[c0 + j] : 0.f;
+#pragma unroll 4
+        for (int i = 0; i < 48; ++i) {
+            const float v = pix[((i >> 2) << 7) + p * 4 + (i & 3)];  // (ci*4+ky)*128 + p*4 + kx
+            const float* wr = wt + i * C + c0;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                if (j < cpt) {
+                    const f32x4 w4 = *(const f32x4*)(wr + j);
+                    acc[j] = fmaf(v, w4[0], acc[j]); acc[j + 1] = fmaf(v, w4[1], acc[j + 1]);
+                    acc[j + 2] = fmaf(v, w4[2], acc[j + 2]); acc[j + 3] = fmaf(v, w4[3], acc[j + 3]);
+                }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += j < cpt ? acc[j] : 0.f;
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < cpt) { acc[j] -= mean; sq += acc[j] * acc[j]; }
+        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+        const float rstd = rsqrtf(sq / (float)C + 1e-5f);
+        if (px < G) {
+            float* o = x + ((size_t)(b * G + py) * G + px) * C + c0;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                if (j < cpt) {
+                    const f32x4 g4 = *(const f32x4*)(gamma + c0 + j), b4 = *(const f32x4*)(beta + c0 + j);
+                    f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
+                    *(f32x4*)(o + j) = v * rstd * g4 + b4;
+                }
+        }
+    }
 }
 
 hipError_t launch_patch_embed(const float* img, const float* w_t, const float* bias, const float* gamma,
                               const float* beta, float* x, int B, int S, int C, hipStream_t s) {
     if (C > 128 || (S & 3)) return hipErrorInvalidValue;
     const int G = S / 4;
-    dim3 grid((G + 31) / 32, G, B), block(256);
+    dim3 grid(G, B), block(256);
     size_t smem = (size_t)(48 * C + 3 * 4 * 128) * sizeof(float);
     hipLaunchKernelGGL(patch_embed_kernel, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, C, G);
     return hipGetLastError();
@@ -90,14 +95,24 @@ hipError_t launch_patch_embed(const float* img, const float* w_t, const float* b
 //     (b, y2, x2) is the concat of x[b, 2y2+dy, 2x2+dx, :] for (dy,dx) = (0,0),(1,0),(0,1),(1,1).
 // =============================================================================================
 //     SPLIT (dtypes BF16X3 / F16X3): the 16-bit output is two planes, hi and lo = v - hi (y_lo elements behind).
-template <typename T, bool MERGE, int NV, bool SPLIT>
+//     LPR = lanes per row: 64, or 32 for C <= 128 (stage 1: a 64-lane wave would keep half its lanes idle on the largest
+//     M of the encoder — two rows per wave instead; the butterfly sums are bit-identical, the upper half only added zeros).
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {     // butterfly over the LPR lanes that share a row
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, bool MERGE, int NV, bool SPLIT, int LPR = 64>
 __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ y16,
                                                           float* __restrict__ y32, int M, int C, float eps, int H,
                                                           int W, int Cin, size_t y_lo, int* __restrict__ flag) {
     typedef typename H16<T>::v4 v4;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int RPW = 64 / LPR;                      // rows per wave
+    const int lane = threadIdx.x & (LPR - 1);
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
     if (row >= M) return;
     const float* src[4];
     if (MERGE) {
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restric
             sum += v[j][0] + v[j][1] + v[j][2] + v[j][3];
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
+    const float mean = row_sum<LPR>(sum) / (float)C;
     float sq = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restric
             sq += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = rsqrtf(row_sum<LPR>(sq) / (float)C + eps);
     // one non-finite input poisons mean and variance of the whole row: rstd is NaN (or 0 for an infinite variance)
     if (flag && lane == 0 && !(rstd > 0.f && rstd < 3.0e38f)) atomicOr(flag, 1);
 #pragma unroll
@@ -164,7 +179,9 @@ template <typename T, bool MERGE, bool SPLIT>
 static void ln_dispatch(dim3 grid, hipStream_t s, const float* x, const float* gamma, const float* beta, T* y16,
                         float* y32, int M, int C, float eps, int H, int W, int Cin, size_t y_lo, int* flag) {
     dim3 block(256);
-    if (C <= 256)
+    if (C <= 128 && !MERGE)     // two rows per wave
+        hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 1, SPLIT, 32>), dim3((grid.x + 1) / 2), block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin, y_lo, flag);
+    else if (C <= 256)
         hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 1, SPLIT>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin, y_lo, flag);
     else if (C <= 512)
         hipLaunchKernelGGL((layernorm16_kernel<T, MERGE, 2, SPLIT>), grid, block, 0, s, x, gamma, beta, y16, y32, M, C, eps, H, W, Cin, y_lo, flag);

@@ -3,16 +3,11 @@
 cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "pipeline or predict or grouped" > gpurun_out/t_pipe.log 2>&1; echo "pytest pipeline rc=$?"; tail -3 gpurun_out/t_pipe.log | cut -c1-300
-for eb in 224 128; do
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub --encode-batch $eb > gpurun_out/bench20_eb$eb.log 2>&1; echo "bench20 eb=$eb rc=$?"; tail -1 gpurun_out/bench20_eb$eb.log | python -c "
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "swin_tiny or batch32 or swin_full" > gpurun_out/t_attn.log 2>&1; echo "pytest enc rc=$?"; tail -3 gpurun_out/t_attn.log | cut -c1-300
+timeout 600 python -m pytest tests/test_gpu_pixels.py -x -q -m gpu -k "fp16x3 and not budget" > gpurun_out/t_pixels.log 2>&1; echo "pytest pixels rc=$?"; tail -3 gpurun_out/t_pixels.log | cut -c1-600
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub > gpurun_out/bench20.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench20.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 print(d['value'], d['roofline']['achieved'], d['roofline']['stage34']['achieved'])
-"
-done
-timeout 300 python bench.py --gpus 1 --no-cpu-baseline --no-sub > gpurun_out/bench512.log 2>&1; echo "bench512 rc=$?"; tail -1 gpurun_out/bench512.log | python -c "
-import sys,json
-d=json.loads(sys.stdin.read())
-print(d['value'], d['roofline']['achieved'], d['roofline']['stage34']['achieved'])
+for e in d['roofline_extra']: print(e['kernel'][:50], e['measured'][:10], e['achieved'], e['frac'], e['avg_launch_us'])
 "
