@@ -65,6 +65,7 @@ struct mnx_engine {
     size_t xn_lo = 0, qkv_lo = 0, attn_lo = 0, h_lo = 0;   // split modes: element offset of each buffer's lo plane
     int split_mask = SPL_ALL;                               // op classes evaluated with all three product terms
     int* enc_flag = nullptr;                                // device: set when the final LayerNorm sees a non-finite row
+    float* zero_bias = nullptr;                             // [2 * widest C] zeros: the bias of the patch-merging reductions
     int tap_item = -1;
     float* tap_dst = nullptr;
     // decoder
@@ -486,6 +487,12 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     if (dt_split(c.compute_dtype)) {
         h->xn_lo = MB * max_xn; h->qkv_lo = MB * max_qkv; h->attn_lo = MB * max_xn; h->h_lo = MB * max_h;
     }
+    {   // the reference's PatchMerging.reduction has no bias; every GEMM kernel adds this vector instead, so that the rows
+        // of a layer that different kernels compute (launch_gemm16 splits by batch size) go through the same additions
+        const size_t nz = (size_t)c.embed_dim << c.n_stages;
+        h->zero_bias = (float*)P.dalloc(nz * sizeof(float));
+        if (h->zero_bias && hipMemset(h->zero_bias, 0, nz * sizeof(float)) != hipSuccess) P.problems.push_back("hipMemset failed");
+    }
     h->enc_flag = (int*)P.dalloc(sizeof(int));
     if (h->enc_flag && hipMemset(h->enc_flag, 0, sizeof(int)) != hipSuccess) P.problems.push_back("hipMemset failed");
     DecBuffers& db = h->db;
@@ -666,7 +673,7 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         }
         if (si + 1 < c.n_stages) {
             HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s, h->xn_lo));
-            HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, h->xn_lo, st.m_w, other, 0, nullptr, nullptr, M / 4, 2 * C, 4 * C, SPL_MERGE));
+            HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, h->xn_lo, st.m_w, other, 0, h->zero_bias, nullptr, M / 4, 2 * C, 4 * C, SPL_MERGE));
             std::swap(cur, other);
             Hh /= 2; Ww /= 2; C *= 2;
             HIPCHK(h, tap((size_t)B * Hh * Ww * C));

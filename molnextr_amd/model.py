@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import weights as W
-from .engine import Engine
+from .engine import Engine, MnxError
 from .preprocess import load_image_rgb, transform_image
 from .tokenizer import get_tokenizer
 
@@ -234,6 +234,9 @@ class molnextr:
                 feats = self.engine.encode(x)
                 preds += decode_batch(self.engine, feats, self.tokenizer, ref_batch_size=batch_size,
                                       compute_confidence=True)
+                if self.engine.encoder_nonfinite():      # fp16 operand range exceeded (mnx_predict reports it by itself)
+                    raise MnxError("encoder features are not finite: an activation left the fp16 range of the operand mode "
+                                   f"'{self.engine.dtype}'; construct molnextr(..., dtype='bf16x3') for this checkpoint")
         from .chem import convert_graph_to_smiles
         smiles_list, molblock_list, _ = convert_graph_to_smiles(
             [p["chartok_coords"]["coords"] for p in preds], [p["chartok_coords"]["symbols"] for p in preds],
