@@ -276,6 +276,9 @@ hipError_t launch_cast16(int dtype, const float* x, void* y16, size_t n, hipStre
 //     order of that MFMA is permuted identically on both operands so no data movement is needed.
 // =============================================================================================
 constexpr int WS = 12, WN = 144, HD = 32;
+#ifndef MNX_ATTN_STAMP          // tools/attn_lab defines it to record per-workgroup cycle counters; nothing in the product
+#define MNX_ATTN_STAMP(i)
+#endif
 constexpr int KS_STRIDE = 40;    // elements per K row in LDS (80 B: conflict-free ds_read_b128)
 constexpr int VT_STRIDE = 168;   // elements per V^T row in LDS (336 B: conflict-free ds_read_b64), keys 144..167 zero
 
@@ -443,6 +446,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
     const int wy = bid % nWh;
     const int b = bid / nWh;
 
+    MNX_ATTN_STAMP(0);
     const bool last_y = shift > 0 && wy == nWh - 1, last_x = shift > 0 && wx == nWw - 1;
     for (int t = tid; t < WN; t += NTHR) {
         const int ty = t / WS, tx = t % WS;
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
         Vt[pl][(j / (VT_STRIDE - WN)) * VT_STRIDE + WN + j % (VT_STRIDE - WN)] = (T)0.f;
     }
     __syncthreads();
+    MNX_ATTN_STAMP(1);
 
     const size_t ld = (size_t)3 * C;
     for (int i = tid; i < 2 * WN * 4; i += NTHR) {       // 576 16-byte chunks each for K and V, two planes
@@ -474,7 +479,9 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
     const int qrow = rowof[wave * 16 + fr];
     const v8 qh = *(const v8*)(qkv + (size_t)qrow * ld + head * HD + fg * 8);
     const v8 ql = *(const v8*)(qkv + qkv_lo + (size_t)qrow * ld + head * HD + fg * 8);
+    MNX_ATTN_STAMP(2);
     __syncthreads();
+    MNX_ATTN_STAMP(3);
 
     const bool x3 = terms == 3;
     f32x4 acc[9];
@@ -491,6 +498,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
     }
 
     const float scale = 0.17677669529663687f;
+    MNX_ATTN_STAMP(4);
     const int qinfo = kinfo[wave * 16 + fr];
     const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS);
     const int rq = qinfo >> 16;
@@ -521,6 +529,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv_sum = 1.0f / sum;
+    MNX_ATTN_STAMP(5);
 
     f32x4 oacc[2];
     oacc[0] = oacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -548,6 +557,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
             oacc[dt] = H16<T>::mfma(vh, ph, oacc[dt]);
         }
     }
+MNX_ATTN_STAMP(6);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         v4 hi, lo;
@@ -556,6 +566,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
         *(v4*)(out + o) = hi;
         *(v4*)(out + out_lo + o) = lo;
     }
+    MNX_ATTN_STAMP(7);
 }
 
 hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,
