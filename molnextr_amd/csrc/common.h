@@ -124,3 +124,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
 }
+
+// one 16-byte-per-lane LDS-DMA: LDS[lds + 16 lane] <- sbase[voff] (scalar base, 32-bit lane offset: no 64-bit VGPR address;
+// the builtin form made hipcc keep a zero-extended 64-bit copy of every lane offset and spill them — scratch traffic
+// would also break the vmcnt bookkeeping). M0 (the LDS address of an LDS-DMA) is a reserved register that the compiler
+// neither tracks nor preserves around inline asm: a kernel that uses these helpers issues EVERY LDS-DMA through them
+// and uses nothing else that reads M0 (tests/test_device_math.py checks the generated ISA for both).
+__device__ __forceinline__ void dma16(unsigned voff, const char* sbase, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma4(unsigned voff, const char* sbase, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+typedef __attribute__((address_space(3))) char lds_char_t;

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
             oacc[dt] = H16<T>::mfma(vh, ph, oacc[dt]);
         }
     }
-MNX_ATTN_STAMP(6);
+    MNX_ATTN_STAMP(6);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         v4 hi, lo;
@@ -569,12 +569,281 @@ MNX_ATTN_STAMP(6);
     MNX_ATTN_STAMP(7);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4p  persistent, double-buffered form of the split-operand window attention.
+// tools/attn_lab (per-workgroup clock stamps) showed where window_attn_split_kernel's time goes: a workgroup lives 13 us, 6 of
+// them in three SERIAL memory round trips (bias table -> K / V rows -> q rows) with ~1.5 workgroups resident per CU to
+// hide them (nine-wave workgroups do not pack three to a CU). Here a workgroup stays on its CU and walks a contiguous
+// range of (window, head) items; while item i is multiplied, item i+1's K and V rows (both planes, 36 KB) arrive by
+// LDS-DMA in the other half of a double buffer, its q rows and bias column in registers:
+//   * K / V rows sit ROW-major in LDS (64 bytes per key, no register staging, no transposing writes); the V^T operand
+//     of O^T = V^T.P^T comes from ds_read_b64_tr_b16 (gfx950's transposing LDS read: the 16 lanes of a group hand in
+//     four rows x four 8-byte pieces and receive columns; tools/probes/ds_read_tr_b16.hip prints the mapping). The
+//     16-byte pieces of V row r are stored at piece ^ ((r >> 2) & 3) — the DMA lane simply fetches a different global
+//     piece — which leaves the transposing read at its 2-way (= optimal, 512 bytes over 64 banks) conflict level.
+//   * one wait (vmcnt(0)) and one barrier per item: everything outstanding at the top of item i was issued a whole
+//     item earlier (DMA and q of item i; the context STORES of item i-2, which are kept in registers one item longer
+//     for exactly this reason).
+//   * the shift-mask / relative-position key table has four variants (last row / last column of windows): built once.
+// Arithmetic — term order, k-slot assignment, scaling — is window_attn_split_kernel's: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int WA_ARR = WN * HD * 2;                 // bytes of one of K hi, K lo, V hi, V lo (144 rows x 64 B)
+constexpr int WA_BUF = 4 * WA_ARR;                  // one item's K / V
+constexpr int WA_TABN = 576;                        // floats per bias column slot (529 used)
+constexpr int WA_LDS = 2 * WA_BUF + 2 * WA_TABN * 4 + 4 * WN * 4;   // 80640 B: two workgroups per CU
+typedef short s16x4_t __attribute__((__vector_size__(8)));
+
+template <typename T>
+__device__ __forceinline__ typename H16<T>::v8 lds_tr8(const lds_char_t* p, int off0, int off1) {
+    typedef __attribute__((address_space(3))) s16x4_t lv;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv*)(p + off0));
+    const s16x4_t c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv*)(p + off1));
+    typedef typename H16<T>::v4 v4;
+    const v4 x = __builtin_bit_cast(v4, a), y = __builtin_bit_cast(v4, c);
+    return (typename H16<T>::v8){x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+}
+
+template <typename T>
+__global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __restrict__ qkv, size_t qkv_lo,
+                                                               const float* __restrict__ table, T* __restrict__ out,
+                                                               size_t out_lo, int H, int W, int C, int heads, int shift,
+                                                               int n_items) {
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = (float*)(smem + 2 * WA_BUF);               // [2][WA_TABN]
+    int* kinfo4 = (int*)(smem + 2 * WA_BUF + 2 * WA_TABN * 4);   // [4][WN]: (ky*23 + kx) | region id << 16
+    const lds_char_t* lds = (const lds_char_t*)smem;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_char_t*)smem;
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int nWw = W / WS, nWh = H / WS;
+    for (int i = threadIdx.x; i < 4 * WN; i += 576) {
+        const int var = i / WN, t = i % WN, ty = t / WS, tx = t % WS;
+        const int reg = ((var & 2) ? (ty < WS - shift ? 1 : 2) : 0) * 3 + ((var & 1) ? (tx < WS - shift ? 1 : 2) : 0);
+        kinfo4[i] = (ty * (2 * WS - 1) + tx) | (reg << 16);
+    }
+    // Register diet: the loop body needs <= 80 VGPRs for two workgroups per CU (a 9-wave workgroup puts 3 waves on
+    // SIMD 0, two of them 6: 512 / 6). Everything derived from the lane id (fragment coordinates, window coordinates of
+    // the rows a lane fetches, LDS addresses) is therefore RE-derived at each use from an opaque copy of threadIdx.x —
+    // a handful of VALU operations per item — instead of living in registers across the whole item (the compiler hoists
+    // such values out of the loop and then spills them; a scratch reload inside the loop drains the fetch queue).
+    auto thread_id = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    const char* plane0 = (const char*)qkv;
+    const char* plane1 = (const char*)(qkv + qkv_lo);
+
+    const int it0 = (int)((long long)blockIdx.x * n_items / gridDim.x);
+    const int it1 = (int)((long long)(blockIdx.x + 1) * n_items / gridDim.x);
+    if (it0 >= it1) return;
+
+    // the item being fetched (suffix _n): window, head (uniform), then its K / V by DMA and its q rows / bias column
+    // into registers; the item whose context waits to be stored (suffix _p)
+    int head_n = 0, b_n = 0, wy_n = 0, wx_n = 0;
+    auto locate = [&](int it) {
+        head_n = it % heads;
+        int wi = it / heads;
+        wx_n = wi % nWw; wi /= nWw;
+        wy_n = wi % nWh;
+        b_n = wi / nWh;
+    };
+    auto token_row = [&](int key) {                 // row of window token `key` in the [B*H*W, .] buffers (shift folded in)
+        const int ty = (key * 171) >> 11, tx = key - ty * WS;     // key / 12, key % 12 for key < 144
+        int y = wy_n * WS + ty + shift; if (y >= H) y -= H;
+        int x = wx_n * WS + tx + shift; if (x >= W) x -= W;
+        return (unsigned)((b_n * H + y) * W + x);
+    };
+    // DMA: wave w moves key rows 16w..16w+15, lane l row 16w + l/4, LDS piece l%4 (K: global piece l%4; V: global
+    // piece (l%4) ^ ((l >> 4) & 3), see above)
+    auto fetch_kv = [&](int buf) {
+        const int lane = thread_id() & 63;
+        const unsigned kb = (token_row(wave * 16 + (lane >> 2)) * 3u * (unsigned)C + (unsigned)(head_n * HD)) * 2u;   // bytes, < 2^32
+        const unsigned offK = kb + (unsigned)C * 2u + (unsigned)(lane & 3) * 16u;
+        const unsigned offV = kb + (unsigned)C * 4u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * WA_BUF + wave * 1024));
+        dma16(offK, plane0, dst);
+        dma16(offK, plane1, dst + WA_ARR);
+        dma16(offV, plane0, dst + 2 * WA_ARR);
+        dma16(offV, plane1, dst + 3 * WA_ARR);
+    };
+    // (all global accesses of the loop are "uniform base + 32-bit lane offset": no 64-bit address registers)
+    const char* outp0 = (const char*)out;
+    const char* outp1 = (const char*)(out + out_lo);
+    v8 qh_n, ql_n;
+    float tab_n;
+    int var_n;
+    unsigned ooff_n;                                // bytes into a context plane; < 2^32 (M*C*2 <= 5.3e8)
+    auto fetch_q = [&]() {                          // MFMA role: query 16w + fr, channel group fg
+        const int tid = thread_id(), fr = tid & 15, fg = (tid >> 4) & 3;
+        const unsigned qrow = token_row(wave * 16 + fr);
+        const unsigned qb = (qrow * 3u * (unsigned)C + (unsigned)(head_n * HD + fg * 8)) * 2u;
+        qh_n = *(const v8*)(plane0 + qb);
+        ql_n = *(const v8*)(plane1 + qb);
+        tab_n = tid < 529 ? *(const float*)((const char*)table + (unsigned)(tid * heads + head_n) * 4u) : 0.f;
+        var_n = shift > 0 ? (wy_n == nWh - 1 ? 2 : 0) + (wx_n == nWw - 1 ? 1 : 0) : 0;
+        ooff_n = (qrow * (unsigned)C + (unsigned)(head_n * HD + fg * 4)) * 2u;
+    };
+
+    v4 ohi_p[2], olo_p[2];
+    unsigned ooff_p = 0;
+    bool have_p = false;
+    int cur = 0;
+    locate(it0);
+    fetch_kv(0);
+    fetch_q();
+    for (int it = it0; it < it1; ++it) {
+        // item `it`: its K / V are in LDS, its q rows / bias column in registers. The prefetched registers pass THROUGH the
+        // wait so that the compiler takes them as complete here and adds no vmcnt wait of its own later in the item
+        // (it cannot see the LDS-DMA in the queue: any wait it adds drains the next item's fetch as well)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qh_n), "+v"(ql_n), "+v"(tab_n) : : "memory");
+        const v8 qh = qh_n, ql = ql_n;
+        const unsigned ooff = ooff_n;
+        const int* kinfo = kinfo4 + var_n * WN;
+        float* tabc = tab + cur * WA_TABN;
+        const int tid = thread_id(), fr = tid & 15, fg = (tid >> 4) & 3;
+        if (tid < 529) tabc[tid] = tab_n;
+        __syncthreads();                                      // every wave's DMA landed; buffer cur^1 is free (item it-1 is done)
+        const bool more = it + 1 < it1;
+        if (more) {
+            locate(it + 1);
+            fetch_kv(cur ^ 1);
+        }
+        if (have_p) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                *(v4*)(outp0 + ooff_p + dt * 32) = ohi_p[dt];
+                *(v4*)(outp1 + ooff_p + dt * 32) = olo_p[dt];
+            }
+        }
+        const char* kv = smem + cur * WA_BUF;
+
+        // ---- S^T[key][query], small terms first -------------------------------------------------
+        f32x4 acc[9];
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+            const v8 kh = *(const v8*)(kv + (kt * 16 + fr) * 64 + fg * 16);
+            const v8 kl = *(const v8*)(kv + WA_ARR + (kt * 16 + fr) * 64 + fg * 16);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = H16<T>::mfma(kl, qh, a);
+            a = H16<T>::mfma(kh, ql, a);
+            acc[kt] = H16<T>::mfma(kh, qh, a);
+        }
+
+        // ---- scale + relative-position bias + shift mask, softmax over keys ----------------------
+        const float scale = 0.17677669529663687f;
+        const int qinfo = kinfo[wave * 16 + fr];
+        const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS);
+        const int rq = qinfo >> 16;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+            const int4 ki4 = *(const int4*)(kinfo + kt * 16 + fg * 4);
+            const int kis[4] = {ki4.x, ki4.y, ki4.z, ki4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sc = acc[kt][r] * scale + tabc[qa - (kis[r] & 0xffff)];
+                if ((kis[r] >> 16) != rq) sc += -100.0f;
+                acc[kt][r] = sc;
+                mx = fmaxf(mx, sc);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(acc[kt][r] - mx) * 1024.0f;
+                acc[kt][r] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv_sum = 1.0f / sum;
+
+        // ---- O^T[d][query] = V^T . P^T over 5 blocks of 32 key slots -------------------------------
+        // k-slot j of lane group fg <-> key 32m + 4fg + j (j < 4) and 32m + 16 + 4fg + (j - 4): the transposing read
+        // of rows 32m (+16) + 4fg .. +3 delivers exactly these for channel d = 16dt + fr. Block 4 has no second half
+        // (keys 144..159): its probabilities are zero, its V slots re-read the first half (finite values).
+        f32x4 oacc[2];
+        oacc[0] = oacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int vrow = (4 * fg + (fr >> 2)) * 64 + (fr & 1) * 8;
+        const int piece0 = (((fr >> 1) & 1) ^ fg) * 16;
+        const lds_char_t* vb = lds + cur * WA_BUF + 2 * WA_ARR + vrow;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const f32x4 p0 = acc[2 * m];
+            const f32x4 p1 = (m < 4) ? acc[m < 4 ? 2 * m + 1 : 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            v4 h0, l0, h1, l1;
+            split16x4<T>(p0, h0, l0);
+            split16x4<T>(p1, h1, l1);
+            const v8 ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            const v8 pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            const int r0 = m * 2048, r1 = m < 4 ? m * 2048 + 1024 : m * 2048;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const lds_char_t* vp = vb + (dt ? (piece0 ^ 32) : piece0);
+                const v8 vl = lds_tr8<T>(vp + WA_ARR, r0, r1);
+                const v8 vh = lds_tr8<T>(vp, r0, r1);
+                oacc[dt] = H16<T>::mfma(vl, ph, oacc[dt]);
+                oacc[dt] = H16<T>::mfma(vh, pl, oacc[dt]);
+                oacc[dt] = H16<T>::mfma(vh, ph, oacc[dt]);
+            }
+            // the next item's q rows / bias column: issued here, not with the DMA, because only now (the first 64 keys'
+            // probabilities are consumed) are there registers for them; the rest of the item covers the latency
+            if (m == 1 && more) fetch_q();
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) split16x4<T>(oacc[dt] * inv_sum, ohi_p[dt], olo_p[dt]);
+        ooff_p = ooff;
+        have_p = true;
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        *(v4*)(outp0 + ooff_p + dt * 32) = ohi_p[dt];
+        *(v4*)(outp1 + ooff_p + dt * 32) = olo_p[dt];
+    }
+}
+
+// > 64 KB of dynamic LDS needs the per-function opt-in, once per device (bit d of `done`: device d has it)
+template <typename K>
+static hipError_t attn_lds_opt_in(K kernel) {
+    static unsigned long long done = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
+    if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
+    return e;
+}
+
 hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,
                               int C, int heads, int shift, hipStream_t s, size_t qkv_lo, size_t out_lo, int terms) {
     if (C != heads * HD || H % WS || W % WS) return hipErrorInvalidValue;
     dim3 grid(B * (H / WS) * (W / WS) * heads);
     if (dt_split(dtype)) {
         if (qkv_lo == 0 || out_lo == 0 || (terms != 1 && terms != 3)) return hipErrorInvalidValue;
+        if (terms == 3) {
+            // persistent form: two 576-thread workgroups per CU (80.6 KB of LDS each), contiguous item ranges
+            const int n_items = (int)grid.x, wgs = n_items < 512 ? n_items : 512;
+            hipError_t e;
+            if (dtype == MNX_DT_F16X3) {
+                if ((e = attn_lds_opt_in(window_attn_pipe_kernel<f16_t>)) != hipSuccess) return e;
+                hipLaunchKernelGGL((window_attn_pipe_kernel<f16_t>), dim3(wgs), dim3(576), WA_LDS, s, (const f16_t*)qkv16, qkv_lo,
+                                   rel_table, (f16_t*)out16, out_lo, H, W, C, heads, shift, n_items);
+            } else {
+                if ((e = attn_lds_opt_in(window_attn_pipe_kernel<bf16_t>)) != hipSuccess) return e;
+                hipLaunchKernelGGL((window_attn_pipe_kernel<bf16_t>), dim3(wgs), dim3(576), WA_LDS, s, (const bf16_t*)qkv16, qkv_lo,
+                                   rel_table, (bf16_t*)out16, out_lo, H, W, C, heads, shift, n_items);
+            }
+            return hipGetLastError();
+        }
         if (dtype == MNX_DT_F16X3)
             hipLaunchKernelGGL((window_attn_split_kernel<f16_t>), grid, dim3(576), 0, s, (const f16_t*)qkv16, qkv_lo, rel_table,
                                (f16_t*)out16, out_lo, H, W, C, heads, shift, terms);

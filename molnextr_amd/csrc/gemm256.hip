@@ -323,18 +323,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 // vmcnt: a wave issues 16 fill instructions per K-tile in the order P1: 2, P2: 4, P3: 2, P4: 4, P5: 2, P6: 2; the number
 // of younger operations allowed at each wait is derived below. First K-tile of the stream and last K-tile of the stream
 // (different in-flight population) drain instead of counting.
-// one 16-byte-per-lane LDS-DMA: LDS[lds + 16 lane] <- sbase[voff] (scalar base, 32-bit lane offset: no 64-bit VGPR address;
-// the builtin form made hipcc keep a zero-extended 64-bit copy of every lane offset and spill them — scratch traffic
-// would also break the vmcnt bookkeeping). M0 (the LDS address of an LDS-DMA) is a reserved register that the compiler
-// neither tracks nor preserves around inline asm: gemm256x3_kernel therefore issues EVERY LDS-DMA through these helpers
-// and uses nothing else that reads M0 (tests/test_device_math.py checks the generated ISA for both).
-__device__ __forceinline__ void dma16(unsigned voff, const char* sbase, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
-}
-__device__ __forceinline__ void dma4(unsigned voff, const char* sbase, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
-}
-typedef __attribute__((address_space(3))) char lds_char_t;
+// (dma16 / dma4, the LDS-DMA helpers every fill of this kernel goes through, live in common.h.)
 
 constexpr int X3_BIAS = 1;                                 // one 4-byte-per-lane DMA per wave per tile (its 64 bias values)
 constexpr int X3_LDS = P_LDS + 8 * 256;                    // + a 256-byte bias patch per wave

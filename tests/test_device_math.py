@@ -100,3 +100,40 @@ def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
             expect.update({63: 3} if "Li2E" in name else {43: 2, 45: 1})
             for w, n in expect.items():
                 assert waits.count(w) >= n and waits.count(w) % n == 0, (name, w, waits.count(w))
+
+
+def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fetch_queue(tmp_path):
+    """window_attn_pipe_kernel (encoder.hip) keeps the next item's K / V LDS-DMA and q loads in flight while the current
+    item is multiplied. That only works if the generated code (1) fits 80 VGPRs with NO scratch (two 9-wave workgroups
+    per CU put 6 waves on SIMD 0; a scratch reload is a vector-memory operation whose wait drains the queue), (2) waits
+    for vector memory exactly once per item — the hand-written vmcnt(0) at the top, plus the compiler's copy of it in
+    front (it waits for the prefetched registers that pass through the asm) — and once more for the prologue, (3) issues
+    4 DMA per item (prologue + loop = 8) through `s_mov_b32 m0` and touches M0 nowhere else, (4) reads V through the
+    transposing LDS read (5 key blocks x 2 channel halves x 2 planes x 2 halves = 40, minus the 4 of the absent second
+    half of block 4, which re-reads the first half: 36)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "molnextr_amd", "csrc", "encoder.hip")
+    out = tmp_path / "encoder.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN3mnx23window_attn_pipe_kernel\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M)
+    assert len(kernels) == 2                                   # fp16 and bf16 planes
+    for name, body in kernels:
+        meta = body
+        assert "scratch_" not in body, name
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 80, name
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) == 0, name
+        n_dma = len(re.findall(r"global_load_lds_dwordx4", body))
+        assert n_dma == 8 and len(re.findall(r"\bm0\b", body)) == n_dma == len(re.findall(r"s_mov_b32 m0,", body)), name
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)
+        assert waits and all(w == "0" for w in waits) and len(waits) <= 3, (name, waits)
+        loop = body[body.index("s_barrier"):]
+        assert len(re.findall(r"s_waitcnt vmcnt", loop)) == 0, name          # nothing between the barrier and the loop's back edge ...
+        assert len(re.findall(r"s_barrier", body)) == 1, name                 # ... and one barrier per item
+        assert len(re.findall(r"ds_read_b64_tr_b16", body)) == 36, name
