@@ -603,11 +603,15 @@ __device__ __forceinline__ typename H16<T>::v8 lds_tr8(const lds_char_t* p, int 
     return (typename H16<T>::v8){x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
 }
 
-template <typename T>
+// MASKED / cls: the windows of a layer come in two kinds — those whose scores need the shift mask (last row / last column
+// of windows of a shifted layer: cls 2, MASKED) and those that do not (cls 0: every window of an unshifted layer, cls 1:
+// the inner windows of a shifted one). They are separate launches of separate instantiations, so that the unmasked ones
+// (most of stages 1-2, all unshifted layers) do not execute the region compare (4 of ~20 VALU operations per score).
+template <typename T, bool MASKED>
 __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __restrict__ qkv, size_t qkv_lo,
                                                                const float* __restrict__ table, T* __restrict__ out,
                                                                size_t out_lo, int H, int W, int C, int heads, int shift,
-                                                               int n_items) {
+                                                               int cls, int n_items) {
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -642,25 +646,38 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
 
     // the item being fetched (suffix _n): window, head (uniform), then its K / V by DMA and its q rows / bias column
     // into registers; the item whose context waits to be stored (suffix _p)
-    int head_n = 0, b_n = 0, wy_n = 0, wx_n = 0;
-    auto locate = [&](int it) {
-        head_n = it % heads;
+    struct Item { int head, b, wy, wx; };            // uniform (scalar registers)
+    auto locate = [=](int it) {
+        Item x;
+        x.head = it % heads;
         int wi = it / heads;
-        wx_n = wi % nWw; wi /= nWw;
-        wy_n = wi % nWh;
-        b_n = wi / nWh;
+        if (cls == 0) {                              // all windows, row-major
+            x.wx = wi % nWw; wi /= nWw;
+            x.wy = wi % nWh;
+            x.b = wi / nWh;
+        } else if (cls == 1) {                       // inner windows: wy < nWh - 1, wx < nWw - 1
+            x.wx = wi % (nWw - 1); wi /= nWw - 1;
+            x.wy = wi % (nWh - 1);
+            x.b = wi / (nWh - 1);
+        } else {                                     // border: the last row of windows (nWw of them), then the last column
+            const int j = wi % (nWh + nWw - 1);
+            x.b = wi / (nWh + nWw - 1);
+            x.wy = j < nWw ? nWh - 1 : j - nWw;
+            x.wx = j < nWw ? j : nWw - 1;
+        }
+        return x;
     };
-    auto token_row = [&](int key) {                 // row of window token `key` in the [B*H*W, .] buffers (shift folded in)
+    auto token_row = [=](const Item& w, int key) {  // row of window token `key` in the [B*H*W, .] buffers (shift folded in)
         const int ty = (key * 171) >> 11, tx = key - ty * WS;     // key / 12, key % 12 for key < 144
-        int y = wy_n * WS + ty + shift; if (y >= H) y -= H;
-        int x = wx_n * WS + tx + shift; if (x >= W) x -= W;
-        return (unsigned)((b_n * H + y) * W + x);
+        int y = w.wy * WS + ty + shift; if (y >= H) y -= H;
+        int x = w.wx * WS + tx + shift; if (x >= W) x -= W;
+        return (unsigned)((w.b * H + y) * W + x);
     };
     // DMA: wave w moves key rows 16w..16w+15, lane l row 16w + l/4, LDS piece l%4 (K: global piece l%4; V: global
     // piece (l%4) ^ ((l >> 4) & 3), see above)
-    auto fetch_kv = [&](int buf) {
+    auto fetch_kv = [&](const Item& w, int buf) {
         const int lane = thread_id() & 63;
-        const unsigned kb = (token_row(wave * 16 + (lane >> 2)) * 3u * (unsigned)C + (unsigned)(head_n * HD)) * 2u;   // bytes, < 2^32
+        const unsigned kb = (token_row(w, wave * 16 + (lane >> 2)) * 3u * (unsigned)C + (unsigned)(w.head * HD)) * 2u;   // bytes, < 2^32
         const unsigned offK = kb + (unsigned)C * 2u + (unsigned)(lane & 3) * 16u;
         const unsigned offV = kb + (unsigned)C * 4u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * WA_BUF + wave * 1024));
@@ -676,24 +693,24 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
     float tab_n;
     int var_n;
     unsigned ooff_n;                                // bytes into a context plane; < 2^32 (M*C*2 <= 5.3e8)
-    auto fetch_q = [&]() {                          // MFMA role: query 16w + fr, channel group fg
+    auto fetch_q = [&](const Item& w) {             // MFMA role: query 16w + fr, channel group fg
         const int tid = thread_id(), fr = tid & 15, fg = (tid >> 4) & 3;
-        const unsigned qrow = token_row(wave * 16 + fr);
-        const unsigned qb = (qrow * 3u * (unsigned)C + (unsigned)(head_n * HD + fg * 8)) * 2u;
+        const unsigned qrow = token_row(w, wave * 16 + fr);
+        const unsigned qb = (qrow * 3u * (unsigned)C + (unsigned)(w.head * HD + fg * 8)) * 2u;
         qh_n = *(const v8*)(plane0 + qb);
         ql_n = *(const v8*)(plane1 + qb);
-        tab_n = tid < 529 ? *(const float*)((const char*)table + (unsigned)(tid * heads + head_n) * 4u) : 0.f;
-        var_n = shift > 0 ? (wy_n == nWh - 1 ? 2 : 0) + (wx_n == nWw - 1 ? 1 : 0) : 0;
-        ooff_n = (qrow * (unsigned)C + (unsigned)(head_n * HD + fg * 4)) * 2u;
+        tab_n = tid < 529 ? *(const float*)((const char*)table + (unsigned)(tid * heads + w.head) * 4u) : 0.f;
+        var_n = MASKED ? (w.wy == nWh - 1 ? 2 : 0) + (w.wx == nWw - 1 ? 1 : 0) : 0;
+        ooff_n = (qrow * (unsigned)C + (unsigned)(w.head * HD + fg * 4)) * 2u;
     };
 
     v4 ohi_p[2], olo_p[2];
     unsigned ooff_p = 0;
     bool have_p = false;
     int cur = 0;
-    locate(it0);
-    fetch_kv(0);
-    fetch_q();
+    Item nx = locate(it0);
+    fetch_kv(nx, 0);
+    fetch_q(nx);
     for (int it = it0; it < it1; ++it) {
         // item `it`: its K / V are in LDS, its q rows / bias column in registers. The prefetched registers pass THROUGH the
         // wait so that the compiler takes them as complete here and adds no vmcnt wait of its own later in the item
@@ -708,8 +725,8 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
         __syncthreads();                                      // every wave's DMA landed; buffer cur^1 is free (item it-1 is done)
         const bool more = it + 1 < it1;
         if (more) {
-            locate(it + 1);
-            fetch_kv(cur ^ 1);
+            nx = locate(it + 1);
+            fetch_kv(nx, cur ^ 1);
         }
         if (have_p) {
 #pragma unroll
@@ -733,19 +750,28 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
         }
 
         // ---- scale + relative-position bias + shift mask, softmax over keys ----------------------
+        // bias index = (qy-ky+11)*23 + (qx-kx+11) = (qy*23+qx + 11*24) - (ky*23+kx). A lane's four keys of a tile
+        // (16 kt + 4 fg + r) are consecutive tokens of one window row (12 % 4 == 0), so their four bias values are
+        // CONSECUTIVE table entries, descending: one index per tile, two paired LDS reads instead of four gathers.
         const float scale = 0.17677669529663687f;
         const int qinfo = kinfo[wave * 16 + fr];
-        const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS);
+        const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS) - 3;
         const int rq = qinfo >> 16;
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < 9; ++kt) {
-            const int4 ki4 = *(const int4*)(kinfo + kt * 16 + fg * 4);
-            const int kis[4] = {ki4.x, ki4.y, ki4.z, ki4.w};
+            int kis[4];
+            if (MASKED) {
+                const int4 ki4 = *(const int4*)(kinfo + kt * 16 + fg * 4);
+                kis[0] = ki4.x; kis[1] = ki4.y; kis[2] = ki4.z; kis[3] = ki4.w;
+            } else {
+                kis[0] = kinfo[kt * 16 + fg * 4];        // region ids are all 0: the entry IS ky*23 + kx
+            }
+            const float* tp = tabc + (qa - (kis[0] & 0xffff));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float sc = acc[kt][r] * scale + tabc[qa - (kis[r] & 0xffff)];
-                if ((kis[r] >> 16) != rq) sc += -100.0f;
+                float sc = acc[kt][r] * scale + tp[3 - r];
+                if (MASKED && (kis[r] >> 16) != rq) sc += -100.0f;
                 acc[kt][r] = sc;
                 mx = fmaxf(mx, sc);
             }
@@ -795,7 +821,7 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
             }
             // the next item's q rows / bias column: issued here, not with the DMA, because only now (the first 64 keys'
             // probabilities are consumed) are there registers for them; the rest of the item covers the latency
-            if (m == 1 && more) fetch_q();
+            if (m == 1 && more) fetch_q(nx);
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) split16x4<T>(oacc[dt] * inv_sum, ohi_p[dt], olo_p[dt]);
@@ -830,18 +856,26 @@ hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_tab
     if (dt_split(dtype)) {
         if (qkv_lo == 0 || out_lo == 0 || (terms != 1 && terms != 3)) return hipErrorInvalidValue;
         if (terms == 3) {
-            // persistent form: two 576-thread workgroups per CU (80.6 KB of LDS each), contiguous item ranges
-            const int n_items = (int)grid.x, wgs = n_items < 512 ? n_items : 512;
-            hipError_t e;
+            // persistent form: two 576-thread workgroups per CU (80.6 KB of LDS each), contiguous item ranges; one launch
+            // for the windows without shift mask, one for the border windows of a shifted layer
+            const int nWh = H / WS, nWw = W / WS;
+            const int n_plain = shift > 0 ? B * (nWh - 1) * (nWw - 1) * heads : (int)grid.x;
+            const int n_border = shift > 0 ? B * (nWh + nWw - 1) * heads : 0;
+#define MNX_ATTN_PIPE(TT, MASKED, CLS, NITEMS)                                                                          \
+    do {                                                                                                                \
+        hipError_t e_ = attn_lds_opt_in(window_attn_pipe_kernel<TT, MASKED>);                                           \
+        if (e_ != hipSuccess) return e_;                                                                                \
+        hipLaunchKernelGGL((window_attn_pipe_kernel<TT, MASKED>), dim3((NITEMS) < 512 ? (NITEMS) : 512), dim3(576), WA_LDS, s,  \
+                           (const TT*)qkv16, qkv_lo, rel_table, (TT*)out16, out_lo, H, W, C, heads, shift, CLS, NITEMS); \
+    } while (0)
             if (dtype == MNX_DT_F16X3) {
-                if ((e = attn_lds_opt_in(window_attn_pipe_kernel<f16_t>)) != hipSuccess) return e;
-                hipLaunchKernelGGL((window_attn_pipe_kernel<f16_t>), dim3(wgs), dim3(576), WA_LDS, s, (const f16_t*)qkv16, qkv_lo,
-                                   rel_table, (f16_t*)out16, out_lo, H, W, C, heads, shift, n_items);
+                if (n_plain > 0) MNX_ATTN_PIPE(f16_t, false, shift > 0 ? 1 : 0, n_plain);
+                if (n_border > 0) MNX_ATTN_PIPE(f16_t, true, 2, n_border);
             } else {
-                if ((e = attn_lds_opt_in(window_attn_pipe_kernel<bf16_t>)) != hipSuccess) return e;
-                hipLaunchKernelGGL((window_attn_pipe_kernel<bf16_t>), dim3(wgs), dim3(576), WA_LDS, s, (const bf16_t*)qkv16, qkv_lo,
-                                   rel_table, (bf16_t*)out16, out_lo, H, W, C, heads, shift, n_items);
+                if (n_plain > 0) MNX_ATTN_PIPE(bf16_t, false, shift > 0 ? 1 : 0, n_plain);
+                if (n_border > 0) MNX_ATTN_PIPE(bf16_t, true, 2, n_border);
             }
+#undef MNX_ATTN_PIPE
             return hipGetLastError();
         }
         if (dtype == MNX_DT_F16X3)

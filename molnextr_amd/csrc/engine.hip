@@ -51,6 +51,11 @@ struct GraphKey {
 
 }  // namespace
 
+#ifndef MNX_PLANE_SKEW
+#define MNX_PLANE_SKEW 4352
+#endif
+static constexpr size_t PLANE_SKEW = MNX_PLANE_SKEW;   // elements (8704 bytes; 16-byte aligned for the LDS-DMA)
+
 struct mnx_engine {
     mnx_config cfg;
     int device = 0;
@@ -480,12 +485,15 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->xb = (float*)P.dalloc(MB * L0 * C0 * 4 / 2);
     // operand bytes per element: 2 (bf16 / fp16), 4 (fp32 parity mode, or the two 16-bit planes of the split modes)
     const size_t es = dt_size(c.compute_dtype);
-    h->xn16 = P.dalloc(MB * max_xn * es);
-    h->qkv16 = P.dalloc(MB * max_qkv * es);
-    h->attn16 = P.dalloc(MB * max_xn * es);
-    h->h16 = P.dalloc(MB * max_h * es);
+    // split modes: the lo plane follows the hi plane after PLANE_SKEW extra elements, so that the two planes of a row
+    // are not a large power of two apart (same HBM channel / bank for every hi / lo pair of a stream)
+    const size_t skew = dt_split(c.compute_dtype) ? PLANE_SKEW : 0;
+    h->xn16 = P.dalloc(MB * max_xn * es + skew * 2);
+    h->qkv16 = P.dalloc(MB * max_qkv * es + skew * 2);
+    h->attn16 = P.dalloc(MB * max_xn * es + skew * 2);
+    h->h16 = P.dalloc(MB * max_h * es + skew * 2);
     if (dt_split(c.compute_dtype)) {
-        h->xn_lo = MB * max_xn; h->qkv_lo = MB * max_qkv; h->attn_lo = MB * max_xn; h->h_lo = MB * max_h;
+        h->xn_lo = MB * max_xn + skew; h->qkv_lo = MB * max_qkv + skew; h->attn_lo = MB * max_xn + skew; h->h_lo = MB * max_h + skew;
     }
     {   // the reference's PatchMerging.reduction has no bias; every GEMM kernel adds this vector instead, so that the rows
         // of a layer that different kernels compute (launch_gemm16 splits by batch size) go through the same additions

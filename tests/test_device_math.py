@@ -123,7 +123,7 @@ def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fe
                    check=True, capture_output=True)
     text = out.read_text()
     kernels = re.findall(r"^(_ZN3mnx23window_attn_pipe_kernel\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M)
-    assert len(kernels) == 2                                   # fp16 and bf16 planes
+    assert len(kernels) == 4                                   # {fp16, bf16} planes x {windows without, with} shift mask
     for name, body in kernels:
         meta = body
         assert "scratch_" not in body, name
