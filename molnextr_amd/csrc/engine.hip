@@ -69,7 +69,6 @@ struct mnx_engine {
     void *xn16 = nullptr, *qkv16 = nullptr, *attn16 = nullptr, *h16 = nullptr;
     size_t xn_lo = 0, qkv_lo = 0, attn_lo = 0, h_lo = 0;   // split modes: element offset of each buffer's lo plane
     int split_mask = SPL_ALL;                               // op classes evaluated with all three product terms
-    int enc_chunk = 0;                                      // images per chunk of the HBM-bound encoder stages (0: whole group)
     int* enc_flag = nullptr;                                // device: set when the final LayerNorm sees a non-finite row
     float* zero_bias = nullptr;                             // [2 * widest C] zeros: the bias of the patch-merging reductions
     int tap_item = -1;
@@ -293,7 +292,6 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     mnx_engine* h = new mnx_engine();
     h->cfg = *cfg;
     h->device = device;
-    if (const char* ch = getenv("MNX_ENC_CHUNK")) h->enc_chunk = atoi(ch);
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
     Packer P;
@@ -660,68 +658,30 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         return timed(1, (double)M * Cc * (4.0 + (y16 ? es : 0.0) + (y32 ? 4.0 : 0.0)),
                      [&]() { return launch_layernorm16(dt, x, g, b, y16, y32, M, Cc, 1e-5f, s, h->xn_lo, y32 ? h->enc_flag : nullptr); });
     };
-    // One Swin stage for images [img0, img0 + nimg) of the group: x = the stage's residual stream [B*L, C] (fp32). The
-    // 16-bit temporaries (LN output, qkv, attention output, MLP hidden) always start at the head of their buffers.
-    auto run_blocks = [&](int si, int Hs, int Ws, int Cs, int img0, int nimg, float* x) -> int {
+    HIPCHK(h, timed(3, (double)B * (3.0 * c.img_size * c.img_size + (double)Hh * Ww * C) * 4.0,
+                    [&]() { return launch_patch_embed(images, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta, cur, B, c.img_size, C, s); }));
+    HIPCHK(h, tap((size_t)B * Hh * Ww * C));
+    for (int si = 0; si < c.n_stages; ++si) {
         StageW& st = h->stages[si];
-        const int M = nimg * Hs * Ws;
-        float* xc = x + (size_t)img0 * Hs * Ws * Cs;
+        const int M = B * Hh * Ww;
         for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
             const BlockW& w = st.blocks[bi];
             const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
-            HIPCHK(h, ln(xc, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, Cs));
-            HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, h->xn_lo, w.qkv_w, h->qkv16, h->qkv_lo, w.qkv_b, nullptr, M, 3 * Cs, Cs, SPL_QKV));
-            HIPCHK(h, timed(2, (double)M * Cs * 4.0 * es, [&]() {
-                return launch_window_attn(dt, h->qkv16, w.table, h->attn16, nimg, Hs, Ws, Cs, st.heads, shift, s, h->qkv_lo,
+            HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C));
+            HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, h->xn_lo, w.qkv_w, h->qkv16, h->qkv_lo, w.qkv_b, nullptr, M, 3 * C, C, SPL_QKV));
+            HIPCHK(h, timed(2, (double)M * C * 4.0 * es, [&]() {
+                return launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s, h->qkv_lo,
                                           h->attn_lo, (h->split_mask & SPL_ATTN) ? 3 : 1);
             }));
-            HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, h->attn_lo, w.proj_w, xc, 0, w.proj_b, xc, M, Cs, Cs, SPL_PROJ));
-            HIPCHK(h, ln(xc, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, Cs));
-            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, h->xn_lo, w.fc1_w, h->h16, h->h_lo, w.fc1_b, nullptr, M, 4 * Cs, Cs, SPL_FC1));
-            HIPCHK(h, gemm(EPI_RESID_F32, h->h16, h->h_lo, w.fc2_w, xc, 0, w.fc2_b, xc, M, Cs, 4 * Cs, SPL_FC2));
-            if (nimg == B) HIPCHK(h, tap((size_t)M * Cs));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, h->attn_lo, w.proj_w, cur, 0, w.proj_b, cur, M, C, C, SPL_PROJ));
+            HIPCHK(h, ln(cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C));
+            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, h->xn_lo, w.fc1_w, h->h16, h->h_lo, w.fc1_b, nullptr, M, 4 * C, C, SPL_FC1));
+            HIPCHK(h, gemm(EPI_RESID_F32, h->h16, h->h_lo, w.fc2_w, cur, 0, w.fc2_b, cur, M, C, 4 * C, SPL_FC2));
+            HIPCHK(h, tap((size_t)M * C));
         }
-        return MNX_OK;
-    };
-    // patch merging of images [img0, img0 + nimg): x [B*L, C] -> y [B*L/4, 2C]
-    auto run_merge = [&](int si, int Hs, int Ws, int Cs, int img0, int nimg, const float* x, float* y) -> int {
-        StageW& st = h->stages[si];
-        const size_t r0 = (size_t)img0 * Hs * Ws;
-        HIPCHK(h, launch_merge_ln16(dt, x + r0 * Cs, st.m_g, st.m_b, h->xn16, nimg, Hs, Ws, Cs, 1e-5f, s, h->xn_lo));
-        HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, h->xn_lo, st.m_w, y + r0 / 4 * (2 * Cs), 0, h->zero_bias, nullptr, nimg * Hs * Ws / 4,
-                       2 * Cs, 4 * Cs, SPL_MERGE));
-        return MNX_OK;
-    };
-    // Stages whose layers are HBM-bound (C < 512: Swin-B stages 1 and 2, 2.4 - 6 GB per layer at 224 images) run over
-    // chunks of `enc_chunk` images, so that what one kernel writes the next one still finds in the 256 MB Infinity
-    // Cache; the MFMA-bound stages run over the whole launch group (their GEMMs want all the rows they can get). The
-    // result does not depend on the chunking (every kernel is batch-invariant). No chunking while a tap is set.
-    int n_chunked = 0;
-    const int CH = h->enc_chunk;
-    if (CH > 0 && B > CH && !h->tap_dst)
-        for (int si = 0, Cs = C; si + 1 < c.n_stages && Cs < 512; ++si, Cs *= 2) ++n_chunked;
-    const int img_floats = 3 * c.img_size * c.img_size;
-    for (int img0 = 0; img0 < B; img0 += (n_chunked ? CH : B)) {
-        const int nimg = n_chunked ? std::min(CH, B - img0) : B;
-        HIPCHK(h, timed(3, (double)nimg * (3.0 * c.img_size * c.img_size + (double)Hh * Ww * C) * 4.0, [&]() {
-            return launch_patch_embed(images + (size_t)img0 * img_floats, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta,
-                                      cur + (size_t)img0 * Hh * Ww * C, nimg, c.img_size, C, s);
-        }));
-        if (nimg == B) HIPCHK(h, tap((size_t)B * Hh * Ww * C));
-        float *x = cur, *y = other;
-        int Hs = Hh, Ws = Ww, Cs = C;
-        for (int si = 0; si < n_chunked; ++si) {
-            if (run_blocks(si, Hs, Ws, Cs, img0, nimg, x) != MNX_OK) return MNX_ERR_HIP;
-            if (run_merge(si, Hs, Ws, Cs, img0, nimg, x, y) != MNX_OK) return MNX_ERR_HIP;
-            std::swap(x, y);
-            Hs /= 2; Ws /= 2; Cs *= 2;
-        }
-    }
-    for (int si = 0; si < n_chunked; ++si) { std::swap(cur, other); Hh /= 2; Ww /= 2; C *= 2; }
-    for (int si = n_chunked; si < c.n_stages; ++si) {
-        if (run_blocks(si, Hh, Ww, C, 0, B, cur) != MNX_OK) return MNX_ERR_HIP;
         if (si + 1 < c.n_stages) {
-            if (run_merge(si, Hh, Ww, C, 0, B, cur, other) != MNX_OK) return MNX_ERR_HIP;
+            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s, h->xn_lo));
+            HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, h->xn_lo, st.m_w, other, 0, h->zero_bias, nullptr, M / 4, 2 * C, 4 * C, SPL_MERGE));
             std::swap(cur, other);
             Hh /= 2; Ww /= 2; C *= 2;
             HIPCHK(h, tap((size_t)B * Hh * Ww * C));
