@@ -649,7 +649,10 @@ hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, vo
     if (!bias && !(bias = zero_bias(N))) return hipErrorInvalidValue;
     const SplitArgs spv = *sp;
     const int tm = M / TM, tn = N / TN;
-    const int grid = tm * tn < 256 ? tm * tn : 256;
+#ifndef MNX_X3_GRID             // tools/gemm_lab builds variants with fewer workgroups (what bounds the epilogue: the CU or the chip?)
+#define MNX_X3_GRID 256
+#endif
+    const int grid = tm * tn < MNX_X3_GRID ? tm * tn : MNX_X3_GRID;
 #define MNX_G256X3_CASE(TT, E)                                                                                            \
     case E: {                                                                                                             \
         const hipError_t attr = lds_opt_in(gemm256x3_kernel<TT, E>, X3_LDS);                                              \

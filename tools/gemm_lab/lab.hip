@@ -52,6 +52,10 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
         p[i] = ((int)(h & 0xffff) - 32768) * (scale / 32768.f);
     }
 }
+// background HBM traffic for the 'stream' mode: dst = src, 16 bytes per lane
+__global__ void stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 // reference for sampled rows: out[s][n] = epi(sum_k A[row_s][k] * W[n][k] + bias[n]) (+ resid)
 __global__ void ref_rows(const bf16_t* A, const bf16_t* W, const float* bias, const float* resid, const int* rows,
                          int S, int N, int K, int epi, float* out) {
@@ -73,6 +77,28 @@ int main(int argc, char** argv) {
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
     const char* only = (argc > 3 && strcmp(argv[3], "-")) ? argv[3] : nullptr;
     const bool split = argc > 4 && !strcmp(argv[4], "fp16x3");
+    // argv[5] = "stream": while the dispatched kernel is timed, a second stream copies 1 GiB blocks (HBM read + write) with
+    // argv[6] workgroups (default 1024): does the GEMM share a bottleneck with plain HBM traffic?
+    const bool bg = argc > 5 && !strcmp(argv[5], "stream");
+    const int bg_wgs = argc > 6 ? atoi(argv[6]) : 1024;
+    hipStream_t st2 = nullptr;
+    float4 *bsrc = nullptr, *bdst = nullptr;
+    const size_t bn = (size_t)1 << 26;      // float4 elements = 1 GiB
+    hipEvent_t b0, b1;
+    if (bg) {
+        CK(hipStreamCreate(&st2));
+        CK(hipMalloc(&bsrc, bn * 16)); CK(hipMalloc(&bdst, bn * 16));
+        CK(hipMemset(bsrc, 1, bn * 16));
+        CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(stream_copy, dim3(bg_wgs), dim3(256), 0, st2, bsrc, bdst, bn);
+        CK(hipEventRecord(b0, st2));
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(stream_copy, dim3(bg_wgs), dim3(256), 0, st2, bsrc, bdst, bn);
+        CK(hipEventRecord(b1, st2));
+        CK(hipEventSynchronize(b1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, b0, b1));
+        printf("background copy alone: %.2f TB/s (read + write), %d workgroups\n", 10 * 2.0 * bn * 16 / (ms * 1e-3) * 1e-12, bg_wgs);
+    }
     const int dt = split ? mnx::MNX_DT_F16X3 : mnx::MNX_DT_BF16;
     std::vector<Shape> shapes;
     const int L[4] = {9216, 2304, 576, 144}, C[4] = {128, 256, 512, 1024};
@@ -152,12 +178,27 @@ int main(int argc, char** argv) {
                 }
             }
             for (int i = 0; i < 3; ++i) CK(launch(v));     // warm (epi 2 keeps accumulating in place: values irrelevant here)
+            int bg_n = 0;
+            if (bg && v == 1) {
+                CK(hipStreamSynchronize(st));
+                bg_n = (int)(us[0] * iters / 450.0) + 4;          // ~0.45 ms per 1 GiB copy alone: enough to outlast the timed launches
+                CK(hipEventRecord(b0, st2));
+                for (int i = 0; i < bg_n; ++i) hipLaunchKernelGGL(stream_copy, dim3(bg_wgs), dim3(256), 0, st2, bsrc, bdst, bn);
+                CK(hipEventRecord(b1, st2));
+            }
             CK(hipEventRecord(e0, st));
             for (int i = 0; i < iters; ++i) CK(launch(v));
             CK(hipEventRecord(e1, st));
             CK(hipEventSynchronize(e1));
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
+            if (bg && v == 1) {
+                CK(hipEventSynchronize(b1));
+                float bms;
+                CK(hipEventElapsedTime(&bms, b0, b1));
+                printf("   with background copy: %d x 1 GiB in %.2f ms = %.2f TB/s over its whole run (GEMM part %.2f ms)\n", bg_n, bms,
+                       bg_n * 2.0 * bn * 16 / (bms * 1e-3) * 1e-12, ms);
+            }
             us[v] = ms * 1000.0 / iters;
         }
         const double fl = 2.0 * sh.M * sh.N * sh.K;
