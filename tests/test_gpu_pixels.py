@@ -11,7 +11,8 @@ Nothing of the GPU's output is handed to the checker. Per encoder operand mode:
   * `bf16x3` (split bf16 operands): the same logit gate (1e-3); token flips are allowed only where the teacher-forced
     trace proves a near-tie (below);
   * `fp16` / `bf16` (one 16-bit plane per operand, the fastest modes): measured, with gates at 2x the values committed in
-    profiles/r03_pixels_parity.json.
+    profiles/r03_pixels_parity.json; `fp16` additionally against the reference's own evaluation precision (fp16 autocast,
+    tests/golden/pixels_autocast_fp16.*): it has to stay at least as close to the fp32 reference as the reference itself does.
 
 Teacher forcing (mnx_decode_forced) is what makes the 16-bit numbers mean something: the engine is fed the REFERENCE ids,
 so at every step its history, the finish steps of all rows and hence the positional-encoding rows are the
@@ -46,6 +47,8 @@ def gold(golden_dir):
     g = dict(np.load(os.path.join(golden_dir, "pixels_e2e.npz")))
     with open(os.path.join(golden_dir, "pixels_e2e.json")) as f:
         g["preds"] = json.load(f)["preds"]
+    with open(os.path.join(golden_dir, "pixels_autocast_fp16.json")) as f:
+        g["autocast_fp16"] = json.load(f)
     return g
 
 
@@ -193,6 +196,15 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
                     assert atoms_same, (mode, name, b, "tokens agree with the reference but the atom set does not")
             summary[name]["molecules_with_same_atoms_but_a_flipped_bond"] = bond_only   # 7-class argmax near-ties
             summary[name]["molecules_exact_atoms_bonds"] = exact_n
+        if mode == "fp16":
+            # yardstick for the one-plane fp16 mode: the reference's OWN evaluation precision (fp16 autocast, main.py:277,
+            # exps/eval.sh --fp16; tests/golden/pixels_autocast_fp16.*, torch.autocast('cpu') standing in for CUDA's).
+            # The engine's fp16 operand mode must stay at least as close to the reference's fp32 result as that.
+            ac = gold["autocast_fp16"]
+            summary["reference_fp16_autocast"] = {k: ac[k] for k in ("feature_max_err_vs_fp32", "feature_rms_err_vs_fp32",
+                                                                     "molecules_identical")}
+            assert ferr <= ac["feature_max_err_vs_fp32"] and frms <= ac["feature_rms_err_vs_fp32"], (ferr, frms, ac)
+            assert summary["m32"]["molecules_exact_atoms_bonds"] >= ac["molecules_identical"], (summary["m32"], ac)
         _report(mode, summary)
     finally:
         mol.close()

@@ -21,6 +21,8 @@ Fixtures (all small):
   predict_e2e_conf.json  same with compute_confidence=True on B=3: atom / edge / overall scores
   beam_strategy.npz    BeamSearch.advance/update_finished driven with scripted log-probs: back-pointers, ids, scores,
                        surviving images per step, final n-best predictions
+  pixels_autocast_fp16.npz/.json  the same path under the reference's evaluation precision (fp16 autocast, main.py:277):
+                 how far the reference moves ITSELF from its fp32 result (the yardstick for the one-plane operand modes)
   pixels_e2e.npz/.json the PATH AS A UNIT (model.py:107-108): Encoder.forward + Decoder.decode of the reference on
                        W.synthetic_images(32) under synthetic_checkpoint(0) — ids, lengths, token log-probs, first-steps
                        logits, top-1/top-2 margins of every step, atom positions, bond matrices — for one batch of 6
@@ -368,6 +370,36 @@ def gen_pixels(Encoder, Decoder, args, tok, ck):
     print("pixels_e2e: atoms", [len(p["symbols"]) for p in js["m32"]])
 
 
+def gen_autocast(Encoder, Decoder, args, tok, ck):
+    """The reference's own evaluation runs its encoder and decoder under fp16 autocast (main.py:277, exps/eval.sh:29
+    `--fp16`). This records how far THAT moves the result from the fp32 path of pixels_e2e (same images, same weights):
+    strided features, and which of the 32 molecules keep symbols / coordinates / bonds. torch.autocast('cpu', float16) stands
+    in for torch.cuda.amp.autocast (no CUDA here): the same op list is cast, accumulation details differ."""
+    N = 32
+    enc = Encoder(reference_args()).eval()
+    enc.load_state_dict(ck["encoder"], strict=True)
+    dec = Decoder(args, tok).eval()
+    dec.load_state_dict(ck["decoder"], strict=True)
+    img = W.synthetic_images(N)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+        feats = torch.cat([enc(img[i:i + 4])[0] for i in range(0, N, 4)])
+        preds = dec.decode(feats)
+    ref = np.load(os.path.join(GOLD, "pixels_e2e.npz"))["feat_strided"]
+    with open(os.path.join(GOLD, "pixels_e2e.json")) as f:
+        ref_preds = json.load(f)["preds"]["m32"]
+    fs = feats.float()[:, ::9, ::16].numpy().copy()
+    same = [bool(p["chartok_coords"]["symbols"] == r["symbols"] and p["chartok_coords"]["coords"] == r["coords"] and
+                 p["edges"] == r["edges"]) for p, r in zip(preds, ref_preds)]
+    np.savez_compressed(os.path.join(GOLD, "pixels_autocast_fp16.npz"), feat_strided=fs.astype(np.float16))
+    js = {"what": "reference Encoder.forward + Decoder.decode under torch.autocast('cpu', float16) vs its own fp32 run (pixels_e2e)",
+          "feature_max_err_vs_fp32": float(np.abs(fs - ref).max()), "feature_rms_err_vs_fp32": float(np.sqrt(((fs - ref) ** 2).mean())),
+          "molecule_identical_to_fp32": same, "molecules_identical": int(sum(same)),
+          "smiles_identical": int(sum(p["chartok_coords"]["smiles"] == r["smiles"] for p, r in zip(preds, ref_preds)))}
+    with open(os.path.join(GOLD, "pixels_autocast_fp16.json"), "w") as f:
+        json.dump(js, f)
+    print("pixels autocast fp16:", {k: v for k, v in js.items() if k not in ("what", "molecule_identical_to_fp32")})
+
+
 def gen_crop_pad():
     """CropWhite(pad=50) and PadToSquare of the reference's own data_aug.py (imported through a minimal
     albumentations / cv2 stand-in: both classes are pure numpy apart from a constant-border pad) on ragged pages:
@@ -424,6 +456,8 @@ def main():
         gen_beam_strategy()
     if "pixels" in want:
         gen_pixels(Encoder, Decoder, args, tok, ck)
+    if want & {"pixels", "autocast"}:
+        gen_autocast(Encoder, Decoder, args, tok, ck)
     if "crop" in want:
         gen_crop_pad()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}
