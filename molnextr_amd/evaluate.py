@@ -158,7 +158,7 @@ def main(argv=None):
     import pandas as pd
     import torch.distributed as dist
     from . import weights as W
-    from .engine import Engine
+    from .engine import DTYPES, Engine
     from .preprocess import load_image_rgb
     ap = argparse.ArgumentParser(description="MolNexTR test-set inference on MI355X (reference main.py --do_test)")
     ap.add_argument("--data_path", default=".")
@@ -167,7 +167,14 @@ def main(argv=None):
     ap.add_argument("--load_path", required=True,
                     help="checkpoint: reference .pth or .safetensors; 'synthetic' = deterministic test weights")
     ap.add_argument("--batch_size", type=int, default=4, help="per-GPU batch size; inference uses twice that")
+    ap.add_argument("--dtype", default=None, choices=sorted(DTYPES),
+                    help="encoder operand mode; default fp16x3 (every token / atom / bond as the reference's fp32 path)")
+    ap.add_argument("--fp16", action="store_true",
+                    help="the reference's flag (main.py:40, exps/eval.sh: fp16 autocast): without --dtype it selects the one-plane "
+                         "fp16 operand mode, which stays closer to the fp32 result than the reference's autocast path does "
+                         "(tests/test_gpu_pixels.py, tests/golden/pixels_autocast_fp16.json)")
     args = ap.parse_args(argv)
+    dtype = args.dtype or ("fp16" if args.fp16 else "fp16x3")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,7 +184,7 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     from .checkpoint import load_checkpoint               # strict validation, no optimizer state, safetensors-aware
     states = W.synthetic_checkpoint(0) if args.load_path == "synthetic" else load_checkpoint(args.load_path)
-    engine = Engine(states["encoder"], states["decoder"], device=local, max_batch=64)
+    engine = Engine(states["encoder"], states["decoder"], device=local, max_batch=64, dtype=dtype)
     df = pd.read_csv(os.path.join(args.data_path, args.test_file))
     paths = [os.path.join(args.data_path, p) for p in df["file_path"]]
     preds = run_inference(engine, lambda i: load_image_rgb(paths[i]), len(df), args.batch_size, rank, world,
