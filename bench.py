@@ -401,11 +401,13 @@ def main():
                 break
         mfma = {"fp16x3": "v_mfma_f32_16x16x32_f16 x 3 terms", "bf16x3": "v_mfma_f32_16x16x32_bf16 x 3 terms",
                 "bf16": "v_mfma_f32_16x16x32_bf16", "fp16": "v_mfma_f32_16x16x32_f16", "fp32": "v_mfma_f32_16x16x4_f32"}[args.dtype]
-        roofline = {"kernel": f"mnx::gemm_tn_* + mnx::gemm256_kernel ({mfma}, all encoder Linear layers)",
+        roofline = {"kernel": f"mnx::gemm_tn_* + mnx::gemm256*_kernel ({mfma}, all encoder Linear layers)",
                     "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "work": "algorithmic FLOP = 2*M*N*K per launch",
                     "mfma_terms": terms, "frac_of_peak_executed": round(terms * achieved / PEAK_BF16_TFLOPS, 4),
+                    "peak_sustained_measured": {"value": 2220.0, "unit": "TFLOP/s", "how": "register-only MFMA loop on all 256 CUs for "
+                                                "60-120 ms (tools/probes/mfma_rate.hip, DESIGN.md 6.3d); `peak` stays the nominal figure"},
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb, 2 if split else 1)),
                     "images_per_launch": eb,
