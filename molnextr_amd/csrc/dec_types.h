@@ -63,6 +63,7 @@ struct DecWeights {
 struct DecBuffers {
     DecState* st;
     float *x, *q, *ctx, *h;                    // [slots,256] x3, [slots,1024]
+    float *x2, *part;                          // the other residual-stream buffer [slots,256]; w_2 K-slice partials [dff/256][slots,256]
     float *self_k, *self_v;                    // [layers, slots, heads, T, 32]
     float *memory;                             // [32*S, 256]   scratch of one admission
     float *mem_kv;                             // [mem_blocks, layers, K|V, heads, S, 32]

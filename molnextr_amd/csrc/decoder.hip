@@ -95,6 +95,11 @@ hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, fl
 // PRO: 0 plain input | 1 LayerNorm(gamma, beta, eps 1e-6) | 2 token embedding + row-PE, then LayerNorm
 // EPI: 0 q/k/v scatter (q scaled, k/v appended to the self cache at position t[slot])
 //      1 x[r, n] += result (residual, in place)   2 q-scale store   3 GELU store
+//      4 split-K partial: workgroup z = blockIdx.z multiplies k in [256 z, 256 z + 256) only and stores its partial sums
+//        (bias in slice 0) to out[z][r, n]; nothing is added here. Used for w_2 (K = 1024), the one linear that was twice as
+//        slow as the others in a small tick (16 workgroups x 256 KB): the K / 256 slices are summed, in a fixed order
+//        (((p0 + p1) + p2) + p3) + x, by the kernel that reads the residual stream next (PRO 1 of the following layer, which
+//        writes the summed stream to the OTHER stream buffer — its 24 column blocks all read the old one —, or the head).
 constexpr int TN = 32, XS = 260;
 
 struct LinArgs {
@@ -109,8 +114,12 @@ struct LinArgs {
     float* x_write;       // PRO 2: residual stream x [slots, 256] written by column-block 0
     const float* emb;     // PRO 2: [V, 256]
     const float* pe;      // PRO 2: [pe_len, 256]
+    const float* part;    // PRO 1: K-slice partial sums [W2_SLICES][slots, 256] of the previous layer's w_2, to be added to `in`
+                          //        (then x_write receives the summed stream from column-block 0); EPI 4: unused (out = the partials)
     const DecState* st;
     int N, K, T, heads;
+    int part_stride;      // floats between two K-slices of `part` (slots * 256)
+    int n_part;           // number of K slices (K / 256 of the linear that wrote them)
 };
 
 template <int PRO, int EPI>
@@ -128,11 +137,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     // LayerNorm / embedding / staging thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
     const int lrow = tid >> 3, part = tid & 7;
     f32x4 xv[8], wv[8];
-    const float* wsrc = a.W + (size_t)(n0 + lrow) * a.K + part * 4;
+    const int kbeg = EPI == 4 ? (int)blockIdx.z * 256 : 0;             // EPI 4: this workgroup's K slice
+    const int kend = EPI == 4 ? 256 : a.K;                               // (relative to kbeg)
+    const float* wsrc = a.W + (size_t)(n0 + lrow) * a.K + part * 4 + kbeg;
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(wsrc + 32 * j);
     const int4 rv = a.st->rowv[row0 + lrow];         // {slot, t, prev_tok, rank}; dummy beyond n_active
-    const float* src = a.in + (size_t)(row0 + lrow) * a.K + part * 4;
+    const float* src = a.in + (size_t)(row0 + lrow) * a.K + part * 4 + kbeg;
     if (PRO != 2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = *(const f32x4*)(src + 32 * j);
@@ -148,18 +159,31 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = *(const f32x4*)(e + 32 * j) * 16.0f + *(const f32x4*)(p + 32 * j);
     }
+    if (PRO == 1 && a.part) {    // the previous layer's w_2, summed here (fixed order), residual stream included
+        const float* pp = a.part + (size_t)(row0 + lrow) * 256 + part * 4;
+        const size_t ps = (size_t)a.part_stride;
+        f32x4 sum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] = *(const f32x4*)(pp + 32 * j);
+        for (int z = 1; z < a.n_part; ++z) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] += *(const f32x4*)(pp + z * ps + 32 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = sum[j] + xv[j];
+    }
     const bool live = row0 + lrow < n_act;
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
-    for (int k0 = 0; k0 < a.K; k0 += 256) {
+    for (int k0 = 0; k0 < kend; k0 += 256) {
         // ---- xv / wv hold the input slab [32, 256] and the weight tile [32, 256] of this K chunk ----
         if (!live) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (PRO == 2 && blockIdx.x == 0 && live) {
+        if ((PRO == 2 || (PRO == 1 && a.part)) && blockIdx.x == 0 && live) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) *(f32x4*)(a.x_write + (size_t)(row0 + lrow) * 256 + part * 4 + 32 * j) = xv[j];
         }
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
             *(f32x4*)(xs + lrow * XS + part * 4 + 32 * j) = xv[j];
             *(f32x4*)(ws + lrow * XS + part * 4 + 32 * j) = wv[j];
         }
-        if (k0 + 256 < a.K) {                        // next K chunk: in flight during this chunk's MFMAs
+        if (k0 + 256 < kend) {                       // next K chunk: in flight during this chunk's MFMAs
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 wv[j] = *(const f32x4*)(wsrc + k0 + 256 + 32 * j);
@@ -233,8 +257,10 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
         v[u] = (red[(0 * 32 + lrow) * 33 + nc + u] + red[(1 * 32 + lrow) * 33 + nc + u]) +
                (red[(2 * 32 + lrow) * 33 + nc + u] + red[(3 * 32 + lrow) * 33 + nc + u]);
     const int n = n0 + nc;
-    v += bias4;
-    if (EPI == 0) {
+    if (EPI != 4 || blockIdx.z == 0) v += bias4;
+    if (EPI == 4) {
+        *(f32x4*)(a.out + (size_t)blockIdx.z * a.part_stride + (size_t)row * a.N + n) = v;
+    } else if (EPI == 0) {
         const int part_ = n >> 8, ch = n & 255, hd = ch >> 5, d = ch & 31;
         if (part_ == 0) {
             *(f32x4*)(a.out + (size_t)row * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
@@ -370,6 +396,8 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
 // =============================================================================================
 struct HeadArgs {
     const float* x;        // [slots, 256]
+    const float* part;     // K-slice partial sums of the last layer's w_2 (EPI 4 of dec_linear_kernel), added to x here
+    int part_stride, n_part;
     const float* gamma;
     const float* beta;
     const float* wout_t;   // [256, VP]  (output_layer.weight transposed, padded)
@@ -396,6 +424,13 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     const int4 rv = a.st->rowv[row];
     const int n_act = a.st->n_active;
     f32x4 xrow = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
+    {
+        const float* pp = a.part + (size_t)row * 256 + lane * 4;
+        const size_t ps = (size_t)a.part_stride;
+        f32x4 sum = *(const f32x4*)pp;
+        for (int z = 1; z < a.n_part; ++z) sum += *(const f32x4*)(pp + z * ps);
+        xrow = sum + xrow;
+    }
     if (row >= n_act) return;
     const int slot = rv.x, t = rv.y;
     if (wave == 0) {
@@ -547,7 +582,7 @@ __global__ void dec_admit_kernel(DecState* st, const int* slots, const int* rowc
 // ---- host-side enqueue helpers (engine.hip captures the tick into a hipGraph) -----------------
 template <int PRO, int EPI>
 static void lin(hipStream_t s, const LinArgs& a, int slots) {
-    hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dec_linear_kernel<PRO, EPI>), dim3(a.N / TN, slots / ROW_TILE, EPI == 4 ? a.K / 256 : 1), dim3(256), 0, s, a);
 }
 
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s) {
@@ -585,9 +620,15 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         LinArgs a = {};
         a.st = b.st; a.T = T; a.heads = H;
         // LN1 (+ embedding at layer 0) -> q, k, v
-        a.in = b.x; a.W = L.wqkv; a.bias = L.bqkv; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.out = b.q;
-        a.kcache = kc; a.vcache = vc; a.x_write = b.x; a.emb = w.emb; a.pe = w.pe; a.N = 3 * D; a.K = D;
+        // the residual stream alternates between two buffers: layer l > 0 sums (stream of layer l-1) + (its w_2 slices)
+        // while it normalises them, and column-block 0 writes the sum to the other buffer for the rest of layer l
+        float* xin = l == 0 ? b.x : (((l - 1) & 1) ? b.x2 : b.x);
+        float* xl = (l & 1) ? b.x2 : b.x;
+        a.in = xin; a.W = L.wqkv; a.bias = L.bqkv; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.out = b.q;
+        a.kcache = kc; a.vcache = vc; a.x_write = xl; a.emb = w.emb; a.pe = w.pe; a.N = 3 * D; a.K = D;
+        a.part = l == 0 ? nullptr : b.part; a.part_stride = b.slots * D; a.n_part = w.dff / 256;
         if (l == 0) lin<2, 0>(s, a, slots); else lin<1, 0>(s, a, slots);
+        a.part = nullptr;
         AttnArgs at = {};
         at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
         at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32; at.fixed_keys = 0;
@@ -598,10 +639,10 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
             hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(slots * H), dim3(256), 0, s, at);
         }
         // self final_linear + residual
-        a.in = b.ctx; a.W = L.wo; a.bias = L.bo; a.out = b.x; a.N = D; a.K = D;
+        a.in = b.ctx; a.W = L.wo; a.bias = L.bo; a.out = xl; a.N = D; a.K = D;
         lin<0, 1>(s, a, slots);
         // LN2 -> context query
-        a.in = b.x; a.W = L.wq2; a.bias = L.bq2; a.gamma = L.ln2_g; a.beta = L.ln2_b; a.out = b.q;
+        a.in = xl; a.W = L.wq2; a.bias = L.bq2; a.gamma = L.ln2_g; a.beta = L.ln2_b; a.out = b.q;
         lin<1, 2>(s, a, slots);
         at.anc = nullptr;
         at.K = b.mem_kv + (size_t)l * 2 * b.S * D;    // memory K/V: [block][layer][K|V][head][s][32]
@@ -610,16 +651,16 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         at.fixed_keys = b.S; at.cross = 1;
         hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(slots * H), dim3(256), 0, s, at);
         // context final_linear + residual
-        a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = b.x; a.N = D; a.K = D;
+        a.in = b.ctx; a.W = L.wo2; a.bias = L.bo2; a.out = xl; a.N = D; a.K = D;
         lin<0, 1>(s, a, slots);
-        // feed-forward: LN -> w_1 -> GELU -> w_2 -> + residual
-        a.in = b.x; a.W = L.w1; a.bias = L.b1; a.gamma = L.lnf_g; a.beta = L.lnf_b; a.out = b.h; a.N = w.dff; a.K = D;
+        // feed-forward: LN -> w_1 -> GELU -> w_2 (four K slices; summed with the stream by the next reader)
+        a.in = xl; a.W = L.w1; a.bias = L.b1; a.gamma = L.lnf_g; a.beta = L.lnf_b; a.out = b.h; a.N = w.dff; a.K = D;
         lin<1, 3>(s, a, slots);
-        a.in = b.h; a.W = L.w2; a.bias = L.b2; a.out = b.x; a.N = D; a.K = w.dff;
-        lin<0, 1>(s, a, slots);
+        a.in = b.h; a.W = L.w2; a.bias = L.b2; a.out = b.part; a.N = D; a.K = w.dff;
+        lin<0, 4>(s, a, slots);
     }
     HeadArgs h = {};
-    h.x = b.x; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
+    h.x = ((w.layers - 1) & 1) ? b.x2 : b.x; h.part = b.part; h.part_stride = b.slots * D; h.n_part = w.dff / 256; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
     h.eos = 2; h.trace_rows = trace_rows; h.forced = forced;

@@ -509,6 +509,8 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     db.T = c.max_len; db.S = (int)S; db.slots = SL; db.mem_blocks = h->n_chunk_bufs * ROW_TILE; db.kmax = c.max_atoms;
     db.st = (DecState*)P.dalloc(sizeof(DecState));
     db.x = (float*)P.dalloc((size_t)SL * D * 4);
+    db.x2 = (float*)P.dalloc((size_t)SL * D * 4);
+    db.part = (float*)P.dalloc((size_t)(FF / 256) * SL * D * 4);
     db.q = (float*)P.dalloc((size_t)SL * D * 4);
     db.ctx = (float*)P.dalloc((size_t)SL * D * 4);
     db.h = (float*)P.dalloc((size_t)SL * FF * 4);
