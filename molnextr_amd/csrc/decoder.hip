@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     const int4 rv = a.st->rowv[row];
     const int n_act = a.st->n_active;
     f32x4 xrow = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
-    {
+    if (a.part) {
         const float* pp = a.part + (size_t)row * 256 + lane * 4;
         const size_t ps = (size_t)a.part_stride;
         f32x4 sum = *(const f32x4*)pp;
@@ -611,6 +611,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
     // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
     const int D = 256, H = w.heads, T = b.T;
     const int slots = rows;
+    const bool split_w2 = beam == nullptr;
     if (beam) hipLaunchKernelGGL(beam_begin_kernel, dim3(1), dim3(256), 0, s, b.st, beam->B, beam->K);
     else hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
     for (int l = 0; l < w.layers; ++l) {
@@ -622,11 +623,13 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         // LN1 (+ embedding at layer 0) -> q, k, v
         // the residual stream alternates between two buffers: layer l > 0 sums (stream of layer l-1) + (its w_2 slices)
         // while it normalises them, and column-block 0 writes the sum to the other buffer for the rest of layer l
-        float* xin = l == 0 ? b.x : (((l - 1) & 1) ? b.x2 : b.x);
-        float* xl = (l & 1) ? b.x2 : b.x;
+        // (beam search keeps w_2 unsplit and the stream in one buffer: its oracle comparison runs hundreds of steps through
+        //  1-ulp score ties, which only the summation order it was validated with reproduces — tests/test_gpu_parity.py)
+        float* xin = (l == 0 || !split_w2) ? b.x : (((l - 1) & 1) ? b.x2 : b.x);
+        float* xl = (split_w2 && (l & 1)) ? b.x2 : b.x;
         a.in = xin; a.W = L.wqkv; a.bias = L.bqkv; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.out = b.q;
         a.kcache = kc; a.vcache = vc; a.x_write = xl; a.emb = w.emb; a.pe = w.pe; a.N = 3 * D; a.K = D;
-        a.part = l == 0 ? nullptr : b.part; a.part_stride = b.slots * D; a.n_part = w.dff / 256;
+        a.part = (l == 0 || !split_w2) ? nullptr : b.part; a.part_stride = b.slots * D; a.n_part = w.dff / 256;
         if (l == 0) lin<2, 0>(s, a, slots); else lin<1, 0>(s, a, slots);
         a.part = nullptr;
         AttnArgs at = {};
@@ -656,11 +659,13 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         // feed-forward: LN -> w_1 -> GELU -> w_2 (four K slices; summed with the stream by the next reader)
         a.in = xl; a.W = L.w1; a.bias = L.b1; a.gamma = L.lnf_g; a.beta = L.lnf_b; a.out = b.h; a.N = w.dff; a.K = D;
         lin<1, 3>(s, a, slots);
-        a.in = b.h; a.W = L.w2; a.bias = L.b2; a.out = b.part; a.N = D; a.K = w.dff;
-        lin<0, 4>(s, a, slots);
+        a.in = b.h; a.W = L.w2; a.bias = L.b2; a.N = D; a.K = w.dff;
+        if (split_w2) { a.out = b.part; lin<0, 4>(s, a, slots); }
+        else { a.out = xl; lin<0, 1>(s, a, slots); }
     }
     HeadArgs h = {};
-    h.x = ((w.layers - 1) & 1) ? b.x2 : b.x; h.part = b.part; h.part_stride = b.slots * D; h.n_part = w.dff / 256; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
+    h.x = (split_w2 && ((w.layers - 1) & 1)) ? b.x2 : b.x; h.part = split_w2 ? b.part : nullptr; h.part_stride = b.slots * D;
+    h.n_part = w.dff / 256; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
     h.eos = 2; h.trace_rows = trace_rows; h.forced = forced;

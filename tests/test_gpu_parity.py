@@ -324,26 +324,13 @@ def test_beam_search_vs_oracle(eng, dev, synth_ckpt, B, beam, n_best, max_len):
     lens = out["lengths"].cpu().numpy()
     toks = out["tokens"].cpu().numpy()
     sc = out["scores"].cpu().numpy()
-    ties = 0
     for i in range(B):
         assert len(ref.tokens[i]) == n_best
         for r in range(n_best):
-            got = toks[i, r, :lens[i, r]].tolist()
-            if got != ref.tokens[i][r]:
-                # a different hypothesis is acceptable only where the oracle's own choice was a tie: the step at which
-                # the sequences part (or the one before: the swap of two parents shows one token later) must have had a
-                # gap of at most ~2 fp32 ulps among its best K + 1 candidates.
-                t = next((k for k, (a, b) in enumerate(zip(got, ref.tokens[i][r])) if a != b), min(len(got), len(ref.tokens[i][r])))
-                gaps = ref.min_gap[i][max(0, t - 1):t + 2]
-                assert gaps and min(gaps) < 1e-6, f"image {i} rank {r}: sequences part at {t}, oracle gaps there {gaps}"
-                # (past a tie the two searches explore different hypotheses: tokens, scores and decoder outputs of this
-                #  image are no longer comparable; the other images of the batch still are)
-                ties += 1
-                continue
+            assert toks[i, r, :lens[i, r]].tolist() == ref.tokens[i][r], f"image {i} rank {r}"
             assert abs(sc[i, r] - ref.scores[i][r]) < 1e-4 * max(1.0, abs(ref.scores[i][r]))
             n = lens[i, r]
             assert (out["hidden"][i, r, :n].cpu() - ref.hidden[i][r]).abs().max().item() < 1e-3
-    assert ties <= 2, "more than two tie-broken hypotheses in one case: look at it"
     assert all(sc[i, r] >= sc[i, r + 1] for i in range(B) for r in range(n_best - 1))
     # (no 'beam >= greedy' property: an image leaves the search when its TOP beam finishes, so a short hypothesis
     #  can end the search below the score greedy reaches later — observed on these inputs)
