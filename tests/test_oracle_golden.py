@@ -174,6 +174,19 @@ def test_beam_decode_hypotheses_are_ordered_and_grammatical(synth_ckpt):
             assert (seq[1:][prev_x] >= 165).all()                          # grammar mask holds inside the beam
 
 
+def test_beam_decode_records_how_close_its_choices_were(synth_ckpt):
+    """BeamResult.min_gap: per image and step, the smallest score gap among the best K + 1 candidates. Over 160 steps the
+    4 x 3 case of the GPU beam test passes through a gap of ONE fp32 ulp between rank 0 and rank 1 (step 101): an oracle
+    choice that only one particular fp32 summation order reproduces — the reason beam search keeps the arithmetic it was
+    validated with, and a reminder that agreement on such a fixture is agreement to the last bit."""
+    from oracle.beam import beam_decode
+    feats = W.hash_normal("beam_features_4_3", (4, 144, 1024), 0.5)
+    b = beam_decode(feats, synth_ckpt["decoder"], beam=3, n_best=2, max_len=160)
+    assert [len(g) for g in b.min_gap] == [160, 160, 78, 160]              # image 2 leaves the batch at step 78
+    assert all(g >= 0.0 for gaps in b.min_gap for g in gaps)
+    assert b.min_gap[0][100] < 5e-7 and min(b.min_gap[0][:100]) > 1e-5     # decided everywhere before, a tie at step 101
+
+
 def test_oracle_from_pixels_vs_reference_golden(golden_dir, synth_ckpt):
     """The oracle's composition encoder_forward -> greedy_decode on 6 synthetic images against the reference's own
     Encoder + Decoder run on the same pixels (pixels_e2e.*): features, every token, every log-prob."""
