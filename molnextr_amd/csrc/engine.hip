@@ -1120,9 +1120,9 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         if (live.empty()) continue;       // (only possible before the first admission)
         // ---- a group of ticks, then a status snapshot
         // launch the tick graph sized for the alive-row bound (dense active list: idle row tiles are not launched)
-        static const int caps[] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096};
-        int rows_cap = SL;
-        for (int cp : caps) if (cp >= bound) { rows_cap = cp; break; }
+        // (one graph per capacity, captured on first use: multiples of 64 up to 1024 rows, of 128 up to 2048, of 256 beyond)
+        const int cap_step = bound <= 1024 ? 64 : bound <= 2048 ? 128 : 256;
+        const int rows_cap = std::min(SL, (std::max(bound, 1) + cap_step - 1) / cap_step * cap_step);
         hipGraphExec_t exec = nullptr;
         rc = get_tick_graph(h, SL, rows_cap, nullptr, 0, s, &exec);
         if (rc != MNX_OK) return rc;
