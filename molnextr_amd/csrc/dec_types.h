@@ -64,6 +64,7 @@ struct DecBuffers {
     DecState* st;
     float *x, *q, *ctx, *h;                    // [slots,256] x3, [slots,1024]
     float *x2, *part;                          // the other residual-stream buffer [slots,256]; w_2 K-slice partials [dff/256][slots,256]
+    float *fpart;                              // fused tick (dec_fused.hip): two alternating partial buffers [2][16][slots,256]
     float *self_k, *self_v;                    // [layers, slots, heads, T, 32]
     float *memory;                             // [32*S, 256]   scratch of one admission
     float *mem_kv;                             // [mem_blocks, layers, K|V, heads, S, 32]
@@ -109,8 +110,15 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s);
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s);
 // forced: [trace_rows, T] ids or null — teacher forcing of slots 0..trace_rows-1 (test aid, see HeadArgs)
+// fused_tile: 0 = the 8-launches-per-layer tick of decoder.hip (always used by beam search); 4 / 8 / 16 = the three-launches-
+// per-layer tick of dec_fused.hip with that many rows per workgroup
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
-                            int trace_rows, hipStream_t s, const BeamBuffers* beam = nullptr, const int* forced = nullptr);
+                            int trace_rows, hipStream_t s, const BeamBuffers* beam = nullptr, const int* forced = nullptr,
+                            int fused_tile = 0);
+// dec_fused.hip
+hipError_t dec_fused_init();
+hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int rows, int row_tile, hipStream_t s,
+                                    const float** x_final, const float** part_final);
 hipError_t beam_enqueue_init(const DecBuffers& b, const BeamBuffers& bm, int max_len, hipStream_t s);
 hipError_t beam_enqueue_gather(const DecBuffers& b, const BeamBuffers& bm, int out_len, int* o_tokens, int* o_len,
                                float* o_scores, float* o_hidden, hipStream_t s);

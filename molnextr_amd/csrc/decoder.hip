@@ -398,6 +398,8 @@ struct HeadArgs {
     const float* x;        // [slots, 256]
     const float* part;     // K-slice partial sums of the last layer's w_2 (EPI 4 of dec_linear_kernel), added to x here
     int part_stride, n_part;
+    const float* tree_bias;  // fused tick (dec_fused.hip): `part` holds 16 partials of the last w_2, summed pairwise by index
+                             // (the order every consumer of that tick uses), then + this bias [256], then + x; null otherwise
     const float* gamma;
     const float* beta;
     const float* wout_t;   // [256, VP]  (output_layer.weight transposed, padded)
@@ -424,7 +426,18 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     const int4 rv = a.st->rowv[row];
     const int n_act = a.st->n_active;
     f32x4 xrow = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
-    if (a.part) {
+    if (a.tree_bias) {
+        const float* pp = a.part + (size_t)row * 256 + lane * 4;
+        const size_t ps = (size_t)a.part_stride;
+        f32x4 p[16];
+#pragma unroll
+        for (int z = 0; z < 16; ++z) p[z] = *(const f32x4*)(pp + z * ps);
+#pragma unroll
+        for (int w = 1; w < 16; w *= 2)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2 * w) p[i] += p[i + w];
+        xrow = xrow + (p[0] + *(const f32x4*)(a.tree_bias + lane * 4));
+    } else if (a.part) {
         const float* pp = a.part + (size_t)row * 256 + lane * 4;
         const size_t ps = (size_t)a.part_stride;
         f32x4 sum = *(const f32x4*)pp;
@@ -606,15 +619,21 @@ __global__ void beam_begin_kernel(DecState* st, int B, int K);
 __global__ void beam_pick_kernel(DecState* st, BeamBuffers bm, const float* hidden, int* etok, int T, int V, int eos);
 
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
-                            int trace_rows, hipStream_t s, const BeamBuffers* beam, const int* forced) {
+                            int trace_rows, hipStream_t s, const BeamBuffers* beam, const int* forced, int fused_tile) {
     // slots_scan: state slots the begin kernel scans; rows: capacity of the compact active list this tick is
     // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
     const int D = 256, H = w.heads, T = b.T;
     const int slots = rows;
     const bool split_w2 = beam == nullptr;
+    const bool fused = beam == nullptr && fused_tile > 0;
     if (beam) hipLaunchKernelGGL(beam_begin_kernel, dim3(1), dim3(256), 0, s, b.st, beam->B, beam->K);
     else hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
-    for (int l = 0; l < w.layers; ++l) {
+    const float *fx = nullptr, *fp = nullptr;
+    if (fused) {    // three launches per layer (dec_fused.hip); the head sums the last w_2's 16 partials
+        hipError_t e = dec_enqueue_fused_layers(w, b, rows, fused_tile, s, &fx, &fp);
+        if (e != hipSuccess) return e;
+    }
+    for (int l = 0; l < (fused ? 0 : w.layers); ++l) {
         const DecLayerW& L = w.L[l];
         float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;
         float* vc = b.self_v + (size_t)l * b.slots * H * T * 32;
@@ -665,7 +684,8 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
     }
     HeadArgs h = {};
     h.x = (split_w2 && ((w.layers - 1) & 1)) ? b.x2 : b.x; h.part = split_w2 ? b.part : nullptr; h.part_stride = b.slots * D;
-    h.n_part = w.dff / 256; h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
+    h.n_part = w.dff / 256;
+    if (fused) { h.x = fx; h.part = fp; h.tree_bias = w.L[w.layers - 1].b2; } h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
     h.eos = 2; h.trace_rows = trace_rows; h.forced = forced;

@@ -43,9 +43,9 @@ struct StageW {
 // op classes of the split modes (mnx_set_split_terms)
 enum { SPL_QKV = 1, SPL_ATTN = 2, SPL_PROJ = 4, SPL_FC1 = 8, SPL_FC2 = 16, SPL_MERGE = 32, SPL_ALL = 63 };
 struct GraphKey {
-    int slots, rows, trace, forced;
+    int slots, rows, trace, forced, tile;
     bool operator<(const GraphKey& o) const {
-        return std::tie(slots, rows, trace, forced) < std::tie(o.slots, o.rows, o.trace, o.forced);
+        return std::tie(slots, rows, trace, forced, tile) < std::tie(o.slots, o.rows, o.trace, o.forced, o.tile);
     }
 };
 
@@ -93,6 +93,9 @@ struct mnx_engine {
     bool have_tc = false;
     int n_chunk_bufs = 0;
     bool use_graph = true;
+    // greedy ticks of up to dec_fused_max rows run as three launches per layer (dec_fused.hip) on row tiles of dec_tile rows;
+    // larger ones keep the 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_FUSED_MAX)
+    int dec_tile = 4, dec_fused_max = 256, dec_tile_big = 0;
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
     // profiling (bench aid)
     bool profiling = false;
@@ -294,6 +297,15 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->device = device;
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
+    if (const char* e = getenv("MNX_DEC_TILE")) h->dec_tile = atoi(e);              // 0: never use the fused tick
+    if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity on row tiles of dec_tile
+    if (const char* e = getenv("MNX_DEC_TILE_BIG")) h->dec_tile_big = atoi(e);      // row tile beyond that (0: decoder.hip's tick)
+    for (int* t : {&h->dec_tile, &h->dec_tile_big})
+        if (*t != 0 && *t != 4 && *t != 8 && *t != 16) {
+            g_create_error = "mnx_create: MNX_DEC_TILE / MNX_DEC_TILE_BIG must be 0, 4, 8 or 16";
+            delete h;
+            return MNX_ERR_INVALID_ARG;
+        }
     Packer P;
     P.h = h;
     for (int i = 0; i < n_weights; ++i)
@@ -511,6 +523,9 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     db.x = (float*)P.dalloc((size_t)SL * D * 4);
     db.x2 = (float*)P.dalloc((size_t)SL * D * 4);
     db.part = (float*)P.dalloc((size_t)(FF / 256) * SL * D * 4);
+    db.fpart = (float*)P.dalloc((size_t)2 * 16 * SL * D * 4);
+    if (db.fpart && hipMemset(db.fpart, 0, (size_t)2 * 16 * SL * D * 4) != hipSuccess) P.problems.push_back("hipMemset failed");
+    if (dec_fused_init() != hipSuccess) P.problems.push_back("dec_fused_init: LDS opt-in failed");
     db.q = (float*)P.dalloc((size_t)SL * D * 4);
     db.ctx = (float*)P.dalloc((size_t)SL * D * 4);
     db.h = (float*)P.dalloc((size_t)SL * FF * 4);
@@ -693,17 +708,26 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     return MNX_OK;
 }
 
+// row tile of the fused greedy tick for a capacity of `rows` rows (0: the decoder.hip tick)
+static int tick_tile(const mnx_engine* h, int rows) {
+    const mnx_config& c = h->cfg;
+    if (c.dec_ff != 1024 || c.dec_heads != 8 || c.dec_dim != 256 || c.max_len + 1 > 512 || h->db.S > 160) return 0;
+    const int t = rows <= h->dec_fused_max ? h->dec_tile : h->dec_tile_big;
+    return (t > 0 && rows % t == 0) ? t : 0;
+}
+
 static int get_tick_graph(mnx_engine* h, int slots, int rows, float* trace, int trace_rows, hipStream_t s,
                           hipGraphExec_t* out, const int* forced = nullptr) {
     *out = nullptr;
     if (!h->use_graph) return MNX_OK;
-    GraphKey key{slots, rows, trace ? trace_rows : 0, forced ? trace_rows : 0};
+    const int tile = tick_tile(h, rows);
+    GraphKey key{slots, rows, trace ? trace_rows : 0, forced ? trace_rows : 0, tile};
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { *out = it->second; return MNX_OK; }
     hipGraph_t g = nullptr;
     hipGraphExec_t exec = nullptr;
     HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced);
+    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced, tile);
     hipError_t e2 = hipStreamEndCapture(s, &g);
     if (e != hipSuccess || e2 != hipSuccess) {
         h->err = std::string("decode tick capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
@@ -720,7 +744,7 @@ static int run_ticks(mnx_engine* h, hipGraphExec_t exec, int slots, int rows, fl
                      hipStream_t s, const int* forced = nullptr) {
     for (int i = 0; i < n; ++i) {
         if (exec) HIPCHK(h, hipGraphLaunch(exec, s));
-        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced));
+        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced, tick_tile(h, rows)));
     }
     return MNX_OK;
 }

@@ -310,6 +310,67 @@ def test_beam1_equals_greedy(eng, dev):
         assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
 
 
+def _engine_with_tick(synth_ckpt, tile, fused_max=256, tile_big=0, slots=128):
+    """An engine whose greedy tick runs on the given row tile (0: the 8-launches-per-layer tick of decoder.hip)."""
+    from molnextr_amd.engine import Engine
+    keys = {"MNX_DEC_TILE": str(tile), "MNX_DEC_FUSED_MAX": str(fused_max), "MNX_DEC_TILE_BIG": str(tile_big)}
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ.update(keys)
+    try:
+        return Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=slots)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_fused_tick_is_independent_of_the_row_tile_and_matches_the_unfused_tick(eng, dev, synth_ckpt):
+    """dec_fused.hip defines its arithmetic per element (fixed chains, fixed trees), not per thread mapping: row tiles of
+    4, 8 and 16 rows must give BIT-identical hidden states and log-probs; the 8-launches-per-layer tick of decoder.hip sums
+    the same products in another order: same tokens, hidden within 1e-4. Rows finish at different steps (compaction, PE
+    quirk) and run up to position 479 (every prefetch / loop split of the attention)."""
+    feats = eng.encode(W.synthetic_images(32).to(dev))
+    outs = {}
+    for tile in (4, 8, 16, 0):
+        e = _engine_with_tick(synth_ckpt, tile)
+        try:
+            a = e.decode_greedy(feats)
+            b = e.decode_greedy(feats[:5].contiguous(), max_len=480, stop_on_eos=False)
+            outs[tile] = tuple({k: v.cpu() for k, v in o.items() if v is not None} for o in (a, b))
+        finally:
+            e.close()
+    for tile in (8, 16):
+        for x, y in zip(outs[4], outs[tile]):
+            assert torch.equal(x["lengths"], y["lengths"]), f"tile {tile}"
+            for i, n in enumerate(x["lengths"].tolist()):
+                assert torch.equal(x["tokens"][i, :n], y["tokens"][i, :n]), f"tile {tile} row {i}"
+                assert torch.equal(x["hidden"][i, :n], y["hidden"][i, :n]), f"tile {tile} row {i}: hidden states differ bitwise"
+                assert torch.equal(x["token_logp"][i, :n], y["token_logp"][i, :n]), f"tile {tile} row {i}"
+    for x, y in zip(outs[4], outs[0]):
+        assert torch.equal(x["lengths"], y["lengths"])
+        for i, n in enumerate(x["lengths"].tolist()):
+            assert torch.equal(x["tokens"][i, :n], y["tokens"][i, :n]), f"row {i}"
+            assert (x["hidden"][i, :n] - y["hidden"][i, :n]).abs().max().item() < 1e-4
+            assert (x["token_logp"][i, :n] - y["token_logp"][i, :n]).abs().max().item() < 1e-4
+
+
+def test_fused_and_unfused_ticks_mix_in_one_job(eng, dev, synth_ckpt):
+    """mnx_predict picks the tick by capacity: with MNX_DEC_FUSED_MAX=64 a 160-image job starts on the decoder.hip tick
+    (capacity 192) and drains on the fused one. Tokens / atoms / bonds must equal the all-fused and the all-unfused job."""
+    imgs = W.synthetic_images(160, first_index=500).to(dev)
+    res = []
+    for tile, fmax, big in ((4, 64, 0), (4, 4096, 0), (0, 0, 0), (4, 64, 16)):
+        e = _engine_with_tick(synth_ckpt, tile, fmax, big, slots=256)
+        try:
+            res.append({k: v.cpu() for k, v in e.predict(imgs, ref_batch=32).items()})
+        finally:
+            e.close()
+    for r in res[1:]:
+        _same_predictions(res[0], r)
+
+
 @pytest.mark.parametrize("B,beam,n_best,max_len", [(4, 3, 2, 160), (3, 5, 5, 96), (2, 8, 1, 64), (5, 2, 2, 480),
                                                    (8, 5, 2, 128),      # 40 rows: two 32-row tiles
                                                    (32, 5, 1, 96),      # BASELINE config 5: beam 5 x batch 32 = 5 tiles

@@ -3,4 +3,35 @@
 cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "4-3-2-160" > gpurun_out/t_dec.log 2>&1; echo "pytest beam case rc=$?"; tail -3 gpurun_out/t_dec.log | cut -c1-400
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "fused or greedy or decode or predict or chunk or beam1 or end_to_end or pipeline" > gpurun_out/t_dec.log 2>&1; echo "pytest decoder subset rc=$?"; tail -15 gpurun_out/t_dec.log | cut -c1-600
+B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub"
+run() { # name, env...
+  n=$1; shift
+  env "$@" timeout 300 $B > gpurun_out/b_$n.log 2>&1
+  python - <<PY
+import json
+try:
+    d = json.loads(open("gpurun_out/b_$n.log").read().strip().splitlines()[-1])
+    print("$n", d["value"], "mol/s", d["ms_per_step"], "ms/step")
+except Exception as e:
+    print("$n FAILED", e)
+PY
+}
+run fused4_256 MNX_DEC_TILE=4
+run unfused MNX_DEC_TILE=0
+run fused4_256b MNX_DEC_TILE=4
+run unfused_b MNX_DEC_TILE=0
+run fused4_128 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=128
+run fused4_512 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=512
+run fused4_all MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=4096
+run fused8_512 MNX_DEC_TILE=8 MNX_DEC_FUSED_MAX=512
+run fused4_256_big16 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=256 MNX_DEC_TILE_BIG=16
+run fused4_128_big8 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=128 MNX_DEC_TILE_BIG=8
+# tick profile of the "everything fused, tile 4" and default configs
+for cfg in "all MNX_DEC_FUSED_MAX=4096" "def MNX_DEC_FUSED_MAX=256" "big16 MNX_DEC_TILE_BIG=16"; do
+  set -- $cfg
+  (cd /tmp && env $2 timeout 400 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tick_$1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sub > $GRAFT_REPO_ROOT/gpurun_out/prof_tick_$1.log 2>&1)
+  DB=$(find gpurun_out/prof_tick_$1 -name "*.db" | head -1)
+  python tools/tick_profile.py $DB gpurun_out/tick_profile_$1.txt | head -12
+  rm -f $DB
+done

@@ -31,6 +31,8 @@ def main(path, out=None):
         cur["last_end"] = max(cur["last_end"], en)
         if cur["cap"] is None and "dec_linear" in name:
             cur["cap"] = (gy // max(wy, 1)) * 32
+        if "dec_head" in name:                       # one workgroup per row of capacity (fused ticks have no dec_linear)
+            cur["cap"] = gx // max(wx, 1)
     if cur:
         ticks.append(cur)
     by = defaultdict(list)
@@ -46,12 +48,13 @@ def main(path, out=None):
                      f"{statistics.median(x[1] for x in v):11.1f} {statistics.median(x[3] for x in v):11.1f} {v[0][2]:8d}")
     # per-launch view of a tick: median duration of the i-th kernel of the tick, for the smallest and largest capacity
     for cap in (min(k for k in by if k), max(k for k in by if k)):
-        sel = [t for t in ticks if t["cap"] == cap and len(t["seq"]) == 50]
+        nl = statistics.mode(len(t["seq"]) for t in ticks if t["cap"] == cap)
+        sel = [t for t in ticks if t["cap"] == cap and len(t["seq"]) == nl]
         if not sel:
             continue
         lines.append("")
         lines.append(f"tick at rows_cap {cap}: i-th launch, median us over {len(sel)} ticks, workgroups")
-        for i in range(50):
+        for i in range(nl):
             d = sorted(t["seq"][i][1] for t in sel)
             lines.append(f"  {i:2d} {sel[0]['seq'][i][0]:40s} {d[len(d) // 2]:7.2f} {sel[0]['seq'][i][2]:6d}")
     # timeline: 10 ms bins — decode ticks (count, median row capacity, busy) and encoder busy time per bin
