@@ -90,22 +90,23 @@ __device__ __forceinline__ float dot32(const f32x4 (&q)[8], const f32x4 (&k)[8])
 }
 
 // ---- stage prologue: x = stream (+ tree(partials) + bias) or embedding; stream out; LayerNorm(eps 1e-6) -> xs[r][FXS] ----
-// One wave per row at a time, lane c owns columns 4c..4c+3.
-template <int R, int NP, bool EMB>
+// One wave per row at a time (row r on wave r mod NW), lane c owns columns 4c..4c+3.
+template <int R, int NW, int NP, bool EMB>
 __device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int n_act, bool writer, float* xs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RW = (R + NW - 1) / NW;     // rows per wave
+    constexpr int UB = RW < 2 ? RW : 2;       // rows whose loads are in flight together
+    if (wave >= R) return;                    // (wave-uniform; no barrier inside)
     const f32x4 g = ldg4(a.gamma + lane * 4), be = ldg4(a.beta + lane * 4);
     f32x4 bi = {0.f, 0.f, 0.f, 0.f};
     if (NP > 0) bi = ldg4(a.bias_in + lane * 4);
-    constexpr int RW = R / 4;                 // rows per wave
-    constexpr int UB = RW < 2 ? RW : 2;       // rows whose loads are in flight together
 #pragma unroll 1
     for (int i0 = 0; i0 < RW; i0 += UB) {
         f32x4 v[UB];
         f32x4 p[UB][NP > 0 ? NP : 1];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int row = row0 + wave + 4 * (i0 + u);
+            const int row = row0 + wave + NW * (i0 + u);
             if (EMB) {
                 // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
                 const int4 rv = a.st->rowv[row];
@@ -118,7 +119,7 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int r = wave + 4 * (i0 + u), row = row0 + r;
+            const int r = wave + NW * (i0 + u), row = row0 + r;
             f32x4 x = v[u];
             if (!EMB && NP > 0) x = x + (tree_sum<(NP > 0 ? NP : 1)>(p[u]) + bi);
             if (writer && row < n_act) *(f32x4*)(a.xout + (size_t)row * 256 + lane * 4) = x;
@@ -131,58 +132,115 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int
     }
 }
 
-// ---- weight rows [32 rows x 256 k] x NB blocks -> registers -> LDS ws[32 b + lrow][FXS] ----
-// thread (lrow = tid >> 3, part = tid & 7): eight lanes cover one 128-byte segment of a row per load instruction
-template <int NB>
-__device__ __forceinline__ void wload256(f32x4 (&wv)[NB][8], const float* W, const int (&rowbase)[NB]) {
-    const int lrow = threadIdx.x >> 3, part = threadIdx.x & 7;
+// The same for the kernels with 256 threads per row: the four waves of a row share the partial planes (wave rw sums the
+// index block [rw NP / 4, (rw + 1) NP / 4) pairwise = one subtree of the SAME tree), the subtrees meet in LDS (`psum`
+// [R][4][256]) and the row's first wave finishes the sum, writes the stream and normalises. One workgroup barrier inside.
+template <int R, int NP, bool EMB>
+__device__ __forceinline__ void fused_prologue_row4(const FusedArgs& a, int row0, int n_act, bool writer, float* xs, float* psum) {
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 8, rw = (threadIdx.x >> 6) & 3;
+    const int row = row0 + rl;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (EMB) {
+        if (rw == 0) {
+            // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
+            const int4 rv = a.st->rowv[row];
+            x = ldg4(a.emb + (size_t)rv.z * 256 + lane * 4) * 16.0f + ldg4(a.pe + (size_t)rv.w * 256 + lane * 4);
+        }
+    } else {
+        constexpr int Q = NP >= 4 ? NP / 4 : 1;
+        f32x4 p[Q];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const float* src = W + (size_t)(rowbase[b] + lrow) * 256 + part * 4;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wv[b][j] = ldg4(src + 32 * j);
+        for (int z = 0; z < Q; ++z) p[z] = ldg4(a.part_in + (size_t)(rw * Q + z) * a.part_stride + (size_t)row * 256 + lane * 4);
+        if (rw == 0) x = ldg4(a.xin + (size_t)row * 256 + lane * 4);
+        *(f32x4*)(psum + (rl * 4 + rw) * 256 + lane * 4) = tree_sum<Q>(p);
     }
-}
-template <int NB>
-__device__ __forceinline__ void wstore256(const f32x4 (&wv)[NB][8], float* ws) {
-    const int lrow = threadIdx.x >> 3, part = threadIdx.x & 7;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *(f32x4*)(ws + (32 * b + lrow) * FXS + part * 4 + 32 * j) = wv[b][j];
+    __syncthreads();
+    if (rw != 0) return;
+    if (!EMB) {
+        const float* pp = psum + rl * 1024 + lane * 4;
+        const f32x4 t = (*(const f32x4*)pp + *(const f32x4*)(pp + 256)) + (*(const f32x4*)(pp + 512) + *(const f32x4*)(pp + 768));
+        x = x + (t + ldg4(a.bias_in + lane * 4));
+    }
+    if (writer && row < n_act) *(f32x4*)(a.xout + (size_t)row * 256 + lane * 4) = x;
+    const float mean = wave_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 256.0f);
+    x -= mean;
+    const float var = wave_sum((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) * (1.0f / 256.0f);
+    *(f32x4*)(xs + rl * FXS + lane * 4) = x * rsqrtf(var + 1e-6f) * ldg4(a.gamma + lane * 4) + ldg4(a.beta + lane * 4);
 }
 
-// ---- out[r][c] = xs[r][:] . ws[c][:] over K = 256: wave w multiplies k in [64 w, 64 w + 64) as 16 MFMA k-steps
-// (k-slot g of step j of chunk kc <-> k = 64 w + 16 kc + 4 g + j on both operands); the four waves' chains meet in `red`.
-template <int NT, int R>
-__device__ __forceinline__ void mfma_k256(const float* xs, const float* ws, f32x4 (&acc)[NT]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+// ---- NROWS weight rows x 256 k (blocks of 32 consecutive rows of W, block b starting at rowbase[b]) -> registers -> LDS
+// ws[i][FXS]. Thread (lrow = tid >> 3, part = tid & 7): eight lanes cover one 128-byte segment of a row per load instruction.
+template <int NROWS, int NW>
+struct WRegs {
+    static constexpr int RP = NW * 8;                        // rows per pass of the workgroup
+    static constexpr int NPASS = (NROWS + RP - 1) / RP;
+    f32x4 v[NPASS][8];
+};
+template <int NROWS, int NW>
+__device__ __forceinline__ void wload256(WRegs<NROWS, NW>& w, const float* W, const int* rowbase) {
+    const int lrow = threadIdx.x >> 3, part = threadIdx.x & 7;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ps = 0; ps < WRegs<NROWS, NW>::NPASS; ++ps) {
+        const int i = ps * WRegs<NROWS, NW>::RP + lrow;
+        if (i < NROWS) {
+            const float* src = W + (size_t)(rowbase[i >> 5] + (i & 31)) * 256 + part * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w.v[ps][j] = ldg4(src + 32 * j);
+        }
+    }
+}
+template <int NROWS, int NW>
+__device__ __forceinline__ void wstore256(const WRegs<NROWS, NW>& w, float* ws) {
+    const int lrow = threadIdx.x >> 3, part = threadIdx.x & 7;
+#pragma unroll
+    for (int ps = 0; ps < WRegs<NROWS, NW>::NPASS; ++ps) {
+        const int i = ps * WRegs<NROWS, NW>::RP + lrow;
+        if (i < NROWS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(f32x4*)(ws + i * FXS + part * 4 + 32 * j) = w.v[ps][j];
+        }
+    }
+}
+
+// ---- out[r][c] = xs[r][:] . ws[c][:] over K = 256 as FOUR chains: chain kq multiplies k in [64 kq, 64 kq + 64) as 16 MFMA
+// k-steps (k-slot g of step j of chunk kc <-> k = 64 kq + 16 kc + 4 g + j on both operands); the chains meet in `red`.
+// Wave w computes chain w & 3 of the n-tiles of group w >> 2 (NW / 4 groups share the NT tiles).
+template <int NT, int NW> struct TileGroup { static constexpr int TPG = (NT + NW / 4 - 1) / (NW / 4); };
+template <int NT, int R, int NW>
+__device__ __forceinline__ void mfma_k256(const float* xs, const float* ws, f32x4 (&acc)[TileGroup<NT, NW>::TPG]) {
+    constexpr int TPG = TileGroup<NT, NW>::TPG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    const int kq = wave & 3, t0 = (wave >> 2) * TPG;
+#pragma unroll
+    for (int n = 0; n < TPG; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t0 >= NT) return;
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-        const int kb = wave * 64 + kc * 16 + fg * 4;
+        const int kb = kq * 64 + kc * 16 + fg * 4;
         const f32x4 av = *(const f32x4*)(xs + (fr & (R - 1)) * FXS + kb);
-        f32x4 bv[NT];
+        f32x4 bv[TPG];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bv[n] = *(const f32x4*)(ws + (16 * n + fr) * FXS + kb);
+        for (int n = 0; n < TPG; ++n) bv[n] = *(const f32x4*)(ws + (16 * min(t0 + n, NT - 1) + fr) * FXS + kb);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[n][j], acc[n], 0, 0, 0);
+            for (int n = 0; n < TPG; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[n][j], acc[n], 0, 0, 0);
     }
 }
 // D layout: lane (fr, fg) holds rows 4 fg + i, column fr of every n-tile
-template <int NT, int R>
-__device__ __forceinline__ void red_store(const f32x4 (&acc)[NT], float* red) {
+template <int NT, int R, int NW>
+__device__ __forceinline__ void red_store(const f32x4 (&acc)[TileGroup<NT, NW>::TPG], float* red) {
+    constexpr int TPG = TileGroup<NT, NW>::TPG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    const int kq = wave & 3, t0 = (wave >> 2) * TPG;
     constexpr int RS = NT * 16 + 4;
-    if (fg * 4 < R) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+    for (int n = 0; n < TPG; ++n)
+        if (t0 + n < NT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) red[(wave * R + fg * 4 + i) * RS + n * 16 + fr] = acc[n][i];
-    }
+            for (int i = 0; i < 4; ++i)
+                if (fg * 4 + i < R) red[(kq * R + fg * 4 + i) * RS + (t0 + n) * 16 + fr] = acc[n][i];
+        }
 }
 template <int NT, int R>
 __device__ __forceinline__ float red_get(const float* red, int r, int c) {
@@ -191,190 +249,192 @@ __device__ __forceinline__ float red_get(const float* red, int r, int c) {
 }
 
 // ---- [256 n x KW k] weight slice (k columns k0..k0+KW of a [256, ldw] matrix) -> registers -> LDS [n][STR] ----
-template <int KW>
-struct SliceRegs { f32x4 v[KW / 4]; };      // KW = 32: 8 quads per thread, KW = 64: 16
-template <int KW>
-__device__ __forceinline__ void sload(SliceRegs<KW>& s, const float* W, int ldw, int k0) {
-    constexpr int LPR = KW / 4;              // lanes per row
-    constexpr int RPI = 256 / LPR;           // rows per load instruction of the workgroup
-    const int c4 = threadIdx.x % LPR, n0 = threadIdx.x / LPR;
+template <int KW, int NW>
+struct SliceRegs {
+    static constexpr int LPR = KW / 4;                  // lanes per row
+    static constexpr int RPI = NW * 64 / LPR;           // rows per load instruction of the workgroup
+    static constexpr int NPASS = 256 / RPI;
+    f32x4 v[NPASS];
+};
+template <int KW, int NW>
+__device__ __forceinline__ void sload(SliceRegs<KW, NW>& s, const float* W, int ldw, int k0) {
+    typedef SliceRegs<KW, NW> S;
+    const int c4 = threadIdx.x % S::LPR, n0 = threadIdx.x / S::LPR;
 #pragma unroll
-    for (int j = 0; j < 256 / RPI; ++j) s.v[j] = ldg4(W + (size_t)(n0 + RPI * j) * ldw + k0 + c4 * 4);
+    for (int j = 0; j < S::NPASS; ++j) s.v[j] = ldg4(W + (size_t)(n0 + S::RPI * j) * ldw + k0 + c4 * 4);
 }
-template <int KW, int STR>
-__device__ __forceinline__ void sstore(const SliceRegs<KW>& s, float* dst) {
-    constexpr int LPR = KW / 4, RPI = 256 / LPR;
-    const int c4 = threadIdx.x % LPR, n0 = threadIdx.x / LPR;
+template <int KW, int STR, int NW>
+__device__ __forceinline__ void sstore(const SliceRegs<KW, NW>& s, float* dst) {
+    typedef SliceRegs<KW, NW> S;
+    const int c4 = threadIdx.x % S::LPR, n0 = threadIdx.x / S::LPR;
 #pragma unroll
-    for (int j = 0; j < 256 / RPI; ++j) *(f32x4*)(dst + (n0 + RPI * j) * STR + c4 * 4) = s.v[j];
+    for (int j = 0; j < S::NPASS; ++j) *(f32x4*)(dst + (n0 + S::RPI * j) * STR + c4 * 4) = s.v[j];
 }
 
-// ---- partial[row][n] = sum_{k < KW} in[r][k] * wsl[n][k]: wave w owns columns [64 w, 64 w + 64), one chain of KW / 4 steps ----
-template <int KW, int STR, int R>
+// ---- partial[row][n] = sum_{k < KW} in[r][k] * wsl[n][k] (ONE chain of KW / 4 MFMA k-steps per element): the 16 n-tiles are
+// spread over the NW waves ----
+template <int KW, int STR, int R, int NW>
 __device__ __forceinline__ void mfma_slice_store(const float* in /*[R][STR]*/, const float* wsl /*[256][STR]*/, float* out,
                                                  int row0, int n_act) {
+    constexpr int TWV = 16 / NW;     // n-tiles per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-    f32x4 acc[4];
+    f32x4 acc[TWV];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < TWV; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < KW / 16; ++kc) {
         const int kb = kc * 16 + fg * 4;
         const f32x4 av = *(const f32x4*)(in + (fr & (R - 1)) * STR + kb);
-        f32x4 bv[4];
+        f32x4 bv[TWV];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bv[n] = *(const f32x4*)(wsl + (64 * wave + 16 * n + fr) * STR + kb);
+        for (int n = 0; n < TWV; ++n) bv[n] = *(const f32x4*)(wsl + (16 * (wave * TWV + n) + fr) * STR + kb);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[n][j], acc[n], 0, 0, 0);
+            for (int n = 0; n < TWV; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[n][j], acc[n], 0, 0, 0);
     }
-    if (fg * 4 < R) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + fg * 4 + i;
-            if (row < n_act) {
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + fg * 4 + i;
+        if (fg * 4 + i < R && row < n_act) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) out[(size_t)row * 256 + 64 * wave + 16 * n + fr] = acc[n][i];
-            }
+            for (int n = 0; n < TWV; ++n) out[(size_t)row * 256 + 16 * (wave * TWV + n) + fr] = acc[n][i];
         }
     }
 }
 
-// ---- single-query attention of R rows x one head. L = 256 / R lanes per row.
-//   scores: lane li takes keys li, li + L, ...            (dot32, one 128-byte key row per lane)
-//   denominator: 16 chains (keys = c mod 16, ascending) + butterfly 8, 4, 2, 1
-//   P.V: 8 chains (keys = g mod 8, ascending; the new key of self-attention is the last element of its chain)
-//        + butterfly over g bit 0, 1, 2;   ctx = o * (1 / sum)
-// Kb / Vb: the row's cached keys / values [ncache][32]; knew / vnew (self): this step's key / value in LDS.
-template <int R, bool CROSS, int KP, int VP>
+// ---- single-query attention of one head for R rows, 256 threads (4 waves) per row — the arithmetic of round 3's
+// dec_attn_kernel, so that a row's numbers do not depend on R:
+//   scores: thread rt of the row takes keys rt and rt + 256 (dot32, one 128-byte key row per lane)
+//   denominator: per-thread p(rt) + p(rt + 256), wave butterfly, (w0 + w1) + (w2 + w3)
+//   P.V: 32 chains (wave rw, lane group kg: keys 8 rw + kg + 32 i ascending), butterfly over kg, (w0 + w1) + (w2 + w3);
+//        ctx = o * (1 / sum)
+// Kb / Vb: the row's cached keys / values [ncache][32]. Self-attention: this step's key / value (position ncache) never left
+// the workgroup: ks / vs in LDS. Everything that does not depend on this tick's activations is requested by attn_prefetch
+// before the workgroup waits for anything: key rt, and the first VP value rows of the thread's chain.
+template <int VP>
 struct AttnPre {
-    static constexpr int L = 256 / R, NG = L / 8, M = 8 / NG;
-    f32x4 k[KP][8];
-    f32x4 v[M][VP];
+    f32x4 k[8];
+    f32x4 v[VP];
 };
 
-template <int R, bool CROSS, int KP, int VP>
-__device__ __forceinline__ void attn_prefetch(AttnPre<R, CROSS, KP, VP>& pre, const float* Kb, const float* Vb, int ncache) {
-    constexpr int L = 256 / R, NG = L / 8, M = 8 / NG;
-    const int li = threadIdx.x % L, kgl = li >> 3, dq = li & 7;
-    const int last = ncache > 0 ? ncache - 1 : 0;       // clamped: always a valid cache row, unused beyond ncache
+template <int VP>
+__device__ __forceinline__ void attn_prefetch(AttnPre<VP>& pre, const float* Kb, const float* Vb, int ncache) {
+    const int rt = threadIdx.x & 255, rw = rt >> 6, kg = (rt & 63) >> 3, dq = rt & 7;
+    const int last = ncache > 0 ? ncache - 1 : 0;       // clamped: always a row of the slot's cache, unused beyond ncache
+    const int key = min(rt, last);
 #pragma unroll
-    for (int p = 0; p < KP; ++p) {
-        const int key = min(p * L + li, last);
+    for (int i = 0; i < 8; ++i) pre.k[i] = ldg4(Kb + (size_t)key * 32 + i * 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pre.k[p][i] = ldg4(Kb + (size_t)key * 32 + i * 4);
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-        for (int i = 0; i < VP; ++i) {
-            const int key = min(kgl + NG * m + 8 * i, last);
-            pre.v[m][i] = ldg4(Vb + (size_t)key * 32 + dq * 4);
-        }
+    for (int i = 0; i < VP; ++i) pre.v[i] = ldg4(Vb + (size_t)min(rw * 8 + kg + 32 * i, last) * 32 + dq * 4);
 }
 
-template <int R, bool CROSS, int KP, int VP, int PS>
-__device__ __forceinline__ void attn_rows(const AttnPre<R, CROSS, KP, VP>& pre, const float* Kb, const float* Vb, int ncache,
-                                          const float* qs, const float* ks, const float* vs, float* ps_all, float* cs) {
-    constexpr int L = 256 / R, NG = L / 8, M = 8 / NG;
-    const int rl = threadIdx.x / L, li = threadIdx.x % L, kgl = li >> 3, dq = li & 7;
-    float* ps = ps_all + rl * PS;
+struct AttnLds { float *qs, *ks, *vs, *ps, *cs, *redm, *reds, *po; };   // per-kernel LDS arrays, all [R][...]
+
+template <int R, bool CROSS, int VP, int PS>
+__device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* Kb, const float* Vb, int ncache, const AttnLds& m) {
+    const int rl = threadIdx.x >> 8, rt = threadIdx.x & 255, lane = rt & 63, rw = rt >> 6, kg = lane >> 3, dq = lane & 7;
+    float* ps = m.ps + rl * PS;
     const int nkeys = CROSS ? ncache : ncache + 1;
     f32x4 q[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(qs + rl * 32 + i * 4);
+    for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(m.qs + rl * 32 + i * 4);
+    constexpr int NJ = CROSS ? 1 : 2;        // keys per thread: the memory has <= PS_CROSS (< 256) rows
+    float sc[NJ];
     float mx = -3.0e38f;
 #pragma unroll
-    for (int p = 0; p < KP; ++p) {
-        const int key = p * L + li;
+    for (int j = 0; j < NJ; ++j) {
+        const int key = rt + 256 * j;
+        float s = -3.0e38f;
         if (key < ncache) {
-            const float s = dot32(q, pre.k[p]);
-            ps[key] = s;
-            mx = fmaxf(mx, s);
-        }
-    }
-#pragma unroll 2
-    for (int key = KP * L + li; key < ncache; key += L) {
-        f32x4 kv[8];
+            if (j == 0) {
+                s = dot32(q, pre.k);
+            } else {
+                f32x4 kv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kv[i] = ldg4(Kb + (size_t)key * 32 + i * 4);
-        const float s = dot32(q, kv);
-        ps[key] = s;
-        mx = fmaxf(mx, s);
-    }
-    if (!CROSS && li == 0) {                 // the key of this step: never left the workgroup
-        f32x4 kv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(ks + rl * 32 + i * 4);
-        const float s = dot32(q, kv);
-        ps[ncache] = s;
-        mx = fmaxf(mx, s);
-    }
-#pragma unroll
-    for (int o = L / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    for (int key = li; key < ncache; key += L) ps[key] = expf(ps[key] - mx);
-    if (!CROSS && li == 0) ps[ncache] = expf(ps[ncache] - mx);
-    __syncthreads();
-    float sum = 0.f;
-    for (int key = li & 15; key < nkeys; key += 16) sum += ps[key];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    f32x4 o[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const int vg = kgl + NG * m;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < VP; ++i) {
-            const int key = vg + 8 * i;
-            if (key < ncache) {
-                const float pk = ps[key];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pre.v[m][i][e], pk, acc[e]);
+                for (int i = 0; i < 8; ++i) kv[i] = ldg4(Kb + (size_t)key * 32 + i * 4);
+                s = dot32(q, kv);
             }
+        } else if (!CROSS && key == ncache) {
+            f32x4 kv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(m.ks + rl * 32 + i * 4);
+            s = dot32(q, kv);
         }
-#pragma unroll 4
-        for (int key = vg + 8 * VP; key < ncache; key += 8) {
-            const f32x4 vv = ldg4(Vb + (size_t)key * 32 + dq * 4);
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) m.redm[rl * 4 + rw] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(m.redm[rl * 4 + 0], m.redm[rl * 4 + 1]), fmaxf(m.redm[rl * 4 + 2], m.redm[rl * 4 + 3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int key = rt + 256 * j;
+        const float p = key < nkeys ? expf(sc[j] - mx) : 0.f;
+        if (key < PS) ps[key] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) m.reds[rl * 4 + rw] = sum;
+    __syncthreads();
+    sum = (m.reds[rl * 4 + 0] + m.reds[rl * 4 + 1]) + (m.reds[rl * 4 + 2] + m.reds[rl * 4 + 3]);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        const int key = rw * 8 + kg + 32 * i;
+        if (key < ncache) {
             const float pk = ps[key];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(vv[e], pk, acc[e]);
-        }
-        if (!CROSS && vg == (ncache & 7)) {
-            const f32x4 vv = *(const f32x4*)(vs + rl * 32 + dq * 4);
-            const float pk = ps[ncache];
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(pre.v[i][e], pk, o[e]);
+        } else if (!CROSS && key == ncache) {
+            const f32x4 vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
+            const float pk = ps[key];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(vv[e], pk, acc[e]);
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(vv[e], pk, o[e]);
         }
-        o[m] = acc;
     }
-    // butterfly over the chain index g = kgl + NG m: bit by bit from the lowest (lane bits first, then registers)
+#pragma unroll 8
+    for (int key = rw * 8 + kg + 32 * VP; key < nkeys; key += 32) {
+        f32x4 vv;
+        if (!CROSS && key == ncache) vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
+        else vv = ldg4(Vb + (size_t)key * 32 + dq * 4);
+        const float pk = ps[key];
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(vv[e], pk, o[e]);
+    }
 #pragma unroll
-        for (int sh = 8; sh < L; sh <<= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[m][e] += __shfl_xor(o[m][e], sh, 64);
-#pragma unroll
-    for (int w = 1; w < M; w *= 2)
-#pragma unroll
-        for (int m = 0; m < M; m += 2 * w) o[m] += o[m + w];
-    if (kgl == 0) *(f32x4*)(cs + rl * FHS + dq * 4) = o[0] * (1.0f / sum);
+    for (int e = 0; e < 4; ++e) {
+        o[e] += __shfl_xor(o[e], 8, 64);
+        o[e] += __shfl_xor(o[e], 16, 64);
+        o[e] += __shfl_xor(o[e], 32, 64);
+    }
+    if (lane < 8) *(f32x4*)(m.po + (rl * 4 + rw) * 32 + dq * 4) = o;
+    __syncthreads();
+    if (rt < 8) {
+        const float* pp = m.po + rl * 128 + rt * 4;
+        const f32x4 r = (*(const f32x4*)pp + *(const f32x4*)(pp + 32)) + (*(const f32x4*)(pp + 64) + *(const f32x4*)(pp + 96));
+        *(f32x4*)(m.cs + rl * FHS + rt * 4) = r * (1.0f / sum);
+    }
 }
 
 // LDS plan (floats) of the three kernels
 template <int R> struct FaLds {
-    static constexpr int xs = 0, small = xs + R * FXS;            // small: qs, ks, vs [R][32], cs [R][FHS]
-    static constexpr int qs = small, ks = qs + R * 32, vs = ks + R * 32, cs = vs + R * 32;
-    static constexpr int ws = cs + R * FHS;                       // [96][FXS]; after the qkv MFMAs: red | wos | ps
+    static constexpr int xs = 0;
+    static constexpr int qs = xs + R * FXS, ks = qs + R * 32, vs = ks + R * 32, cs = vs + R * 32;   // [R][32] x3, [R][FHS]
+    static constexpr int redm = cs + R * FHS, reds = redm + R * 4, po = reds + R * 4;              // [R][4] x2, [R][4][32]
+    static constexpr int psum = po + R * 128;                     // [R][4][256] subtrees of the prologue
+    static constexpr int ws = psum + R * 1024;                    // [96][FXS]; after the qkv MFMAs: red | wos | ps
     static constexpr int red = ws, wos = red + 4 * R * 100, ps = wos + 256 * FHS;
     static constexpr int end_a = ws + 96 * FXS, end_b = ps + R * PS_SELF;
     static constexpr int total = end_a > end_b ? end_a : end_b;
 };
 template <int R> struct FbLds {
     static constexpr int xs = 0, qs = xs + R * FXS, cs = qs + R * 32;
-    static constexpr int wos = cs + R * FHS;                      // [256][FHS]
+    static constexpr int redm = cs + R * FHS, reds = redm + R * 4, po = reds + R * 4;
+    static constexpr int psum = po + R * 128;                     // [R][4][256] subtrees of the prologue
+    static constexpr int wos = psum + R * 1024;                   // [256][FHS]
     static constexpr int ws = wos + 256 * FHS;                    // [32][FXS]; after the q MFMAs: red | ps
     static constexpr int red = ws, ps = red + 4 * R * 36;
     static constexpr int end_a = ws + 32 * FXS, end_b = ps + R * PS_CROSS;
@@ -391,35 +451,37 @@ template <int R> struct FcLds {
 // =============================================================================================
 // dec_fa: LN1 (+ embedding | + previous FFN partials) -> q, k, v of one head -> self-attention -> Wo partial
 //   models/decoder.py:254-262 (input norm, self_attn, drop + residual), onmt MultiHeadedAttention
+// 256 threads per row (R rows, 256 R threads): the linear parts use all 4 R waves, the attention 4 waves per row.
 // =============================================================================================
 template <int R, bool EMB>
-__global__ __launch_bounds__(256) void dec_fa_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef FaLds<R> Ld;
-    constexpr int L = 256 / R, KP = 2, VP = (R == 4 ? 8 : R == 8 ? 4 : 2);
+    constexpr int VP = 8;
     const int tid = threadIdx.x;
     const int h = blockIdx.x, row0 = blockIdx.y * R;
-    const int4 rv = a.st->rowv[row0 + tid / L];          // {slot, t, prev_tok, rank} of the row this thread attends for
+    const int4 rv = a.st->rowv[row0 + (tid >> 8)];       // {slot, t, prev_tok, rank} of the row this thread attends for
     const int n_act = a.st->n_active;
-    f32x4 wv[3][8];
+    WRegs<96, 4 * R> wv;
     const int rb[3] = {32 * h, 256 + 32 * h, 512 + 32 * h};
-    wload256<3>(wv, a.wqkv, rb);
-    fused_prologue<R, EMB ? 0 : 16, EMB>(a, row0, n_act, h == 0, smem + Ld::xs);
-    wstore256<3>(wv, smem + Ld::ws);
-    SliceRegs<32> wov;
-    sload<32>(wov, a.wo, 256, 32 * h);
+    wload256<96, 4 * R>(wv, a.wqkv, rb);
+    fused_prologue_row4<R, EMB ? 0 : 16, EMB>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum);
+    wstore256<96, 4 * R>(wv, smem + Ld::ws);
+    // requested now, used after the qkv MFMAs: the head's slice of Wo, this thread's key and its first value rows
     const float* Kb = a.kcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
     const float* Vb = a.vcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
-    AttnPre<R, false, KP, VP> pre;
-    attn_prefetch<R, false, KP, VP>(pre, Kb, Vb, rv.y);
+    AttnPre<VP> pre;
+    attn_prefetch<VP>(pre, Kb, Vb, rv.y);
+    SliceRegs<32, 4 * R> wov;
+    sload<32, 4 * R>(wov, a.wo, 256, 32 * h);
     __syncthreads();
-    f32x4 acc[6];
-    mfma_k256<6, R>(smem + Ld::xs, smem + Ld::ws, acc);
+    f32x4 acc[TileGroup<6, 4 * R>::TPG];
+    mfma_k256<6, R, 4 * R>(smem + Ld::xs, smem + Ld::ws, acc);
     __syncthreads();                                     // every wave is done with ws: it becomes red | wos | ps
-    red_store<6, R>(acc, smem + Ld::red);
-    sstore<32, FHS>(wov, smem + Ld::wos);
+    red_store<6, R, 4 * R>(acc, smem + Ld::red);
+    sstore<32, FHS, 4 * R>(wov, smem + Ld::wos);
     __syncthreads();
-    for (int idx = tid; idx < R * 96; idx += 256) {
+    for (int idx = tid; idx < R * 96; idx += 256 * R) {
         const int r = idx / 96, c = idx - r * 96, part = c >> 5, d = c & 31;
         const float v = red_get<6, R>(smem + Ld::red, r, c) + a.bqkv[part * 256 + 32 * h + d];
         if (part == 0) {
@@ -435,10 +497,11 @@ __global__ __launch_bounds__(256) void dec_fa_kernel(FusedArgs a) {
         }
     }
     __syncthreads();
-    attn_rows<R, false, KP, VP, PS_SELF>(pre, Kb, Vb, rv.y, smem + Ld::qs, smem + Ld::ks, smem + Ld::vs, smem + Ld::ps,
-                                         smem + Ld::cs);
+    const AttnLds m = {smem + Ld::qs, smem + Ld::ks, smem + Ld::vs, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm,
+                       smem + Ld::reds, smem + Ld::po};
+    attn_rows<R, false, VP, PS_SELF>(pre, Kb, Vb, rv.y, m);
     __syncthreads();
-    mfma_slice_store<32, FHS, R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    mfma_slice_store<32, FHS, R, 4 * R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
 }
 
 // =============================================================================================
@@ -446,40 +509,42 @@ __global__ __launch_bounds__(256) void dec_fa_kernel(FusedArgs a) {
 //   models/decoder.py:264-276 (query norm, context_attn, drop + residual)
 // =============================================================================================
 template <int R>
-__global__ __launch_bounds__(256) void dec_fb_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef FbLds<R> Ld;
-    constexpr int L = 256 / R, KP = (R == 4 ? 3 : 2), VP = (R == 4 ? 8 : R == 8 ? 4 : 2);
+    constexpr int VP = 5;                                // 144 memory rows = 4.5 x 32: every value row is prefetched
     const int tid = threadIdx.x;
     const int h = blockIdx.x, row0 = blockIdx.y * R;
-    const int mb = a.st->row_mem[row0 + tid / L];
+    const int mb = a.st->row_mem[row0 + (tid >> 8)];
     const int n_act = a.st->n_active;
-    f32x4 wv[1][8];
-    const int rb[1] = {32 * h};
-    wload256<1>(wv, a.wq2, rb);
-    SliceRegs<32> wov;
-    sload<32>(wov, a.wo2, 256, 32 * h);
     const float* Kb = a.memk + (size_t)mb * a.mem_stride + (size_t)h * a.S * 32;
     const float* Vb = Kb + (size_t)a.S * 256;
-    AttnPre<R, true, KP, VP> pre;
-    attn_prefetch<R, true, KP, VP>(pre, Kb, Vb, a.S);
-    fused_prologue<R, 8, false>(a, row0, n_act, h == 0, smem + Ld::xs);
-    wstore256<1>(wv, smem + Ld::ws);
-    sstore<32, FHS>(wov, smem + Ld::wos);
+    AttnPre<VP> pre;
+    attn_prefetch<VP>(pre, Kb, Vb, a.S);               // memory rows: nothing of this tick is needed to ask for them
+    WRegs<32, 4 * R> wv;
+    const int rb[1] = {32 * h};
+    wload256<32, 4 * R>(wv, a.wq2, rb);
+    fused_prologue_row4<R, 8, false>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum);
+    wstore256<32, 4 * R>(wv, smem + Ld::ws);
     __syncthreads();
-    f32x4 acc[2];
-    mfma_k256<2, R>(smem + Ld::xs, smem + Ld::ws, acc);
+    SliceRegs<32, 4 * R> wov;
+    sload<32, 4 * R>(wov, a.wo2, 256, 32 * h);
+    f32x4 acc[TileGroup<2, 4 * R>::TPG];
+    mfma_k256<2, R, 4 * R>(smem + Ld::xs, smem + Ld::ws, acc);
     __syncthreads();
-    red_store<2, R>(acc, smem + Ld::red);
+    red_store<2, R, 4 * R>(acc, smem + Ld::red);
+    sstore<32, FHS, 4 * R>(wov, smem + Ld::wos);
     __syncthreads();
-    for (int idx = tid; idx < R * 32; idx += 256) {
+    for (int idx = tid; idx < R * 32; idx += 256 * R) {
         const int r = idx >> 5, d = idx & 31;
         smem[Ld::qs + r * 32 + d] = (red_get<2, R>(smem + Ld::red, r, d) + a.bq2[32 * h + d]) * QSCALE;
     }
     __syncthreads();
-    attn_rows<R, true, KP, VP, PS_CROSS>(pre, Kb, Vb, a.S, smem + Ld::qs, nullptr, nullptr, smem + Ld::ps, smem + Ld::cs);
+    const AttnLds m = {smem + Ld::qs, nullptr, nullptr, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm, smem + Ld::reds,
+                       smem + Ld::po};
+    attn_rows<R, true, VP, PS_CROSS>(pre, Kb, Vb, a.S, m);
     __syncthreads();
-    mfma_slice_store<32, FHS, R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    mfma_slice_store<32, FHS, R, 4 * R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
 }
 
 // =============================================================================================
@@ -493,26 +558,26 @@ __global__ __launch_bounds__(256) void dec_fc_kernel(FusedArgs a) {
     const int tid = threadIdx.x;
     const int sl = blockIdx.x, row0 = blockIdx.y * R;
     const int n_act = a.st->n_active;
-    f32x4 wv[2][8];
+    WRegs<64, 4> wv;
     const int rb[2] = {FF_SLICE * sl, FF_SLICE * sl + 32};
-    wload256<2>(wv, a.w1, rb);
-    fused_prologue<R, 8, false>(a, row0, n_act, sl == 0, smem + Ld::xs);
-    wstore256<2>(wv, smem + Ld::ws);
-    SliceRegs<64> w2v;
-    sload<64>(w2v, a.w2, a.dff, FF_SLICE * sl);
+    wload256<64, 4>(wv, a.w1, rb);
+    fused_prologue<R, 4, 8, false>(a, row0, n_act, sl == 0, smem + Ld::xs);
+    wstore256<64, 4>(wv, smem + Ld::ws);
+    SliceRegs<64, 4> w2v;
+    sload<64, 4>(w2v, a.w2, a.dff, FF_SLICE * sl);
     __syncthreads();
     f32x4 acc[4];
-    mfma_k256<4, R>(smem + Ld::xs, smem + Ld::ws, acc);
+    mfma_k256<4, R, 4>(smem + Ld::xs, smem + Ld::ws, acc);
     __syncthreads();
-    red_store<4, R>(acc, smem + Ld::red);
-    sstore<64, FFS>(w2v, smem + Ld::w2s);
+    red_store<4, R, 4>(acc, smem + Ld::red);
+    sstore<64, FFS, 4>(w2v, smem + Ld::w2s);
     __syncthreads();
     for (int idx = tid; idx < R * 64; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
         smem[Ld::hs + r * FFS + c] = gelu_erf(red_get<4, R>(smem + Ld::red, r, c) + a.b1[FF_SLICE * sl + c]);
     }
     __syncthreads();
-    mfma_slice_store<64, FFS, R>(smem + Ld::hs, smem + Ld::w2s, a.part_out + (size_t)sl * a.part_stride, row0, n_act);
+    mfma_slice_store<64, FFS, R, 4>(smem + Ld::hs, smem + Ld::w2s, a.part_out + (size_t)sl * a.part_stride, row0, n_act);
 }
 
 // ---- host side -------------------------------------------------------------------------------
@@ -522,26 +587,27 @@ static hipError_t opt_in(K kern, int bytes) {
 }
 
 template <int R>
-static hipError_t fused_init_r() {
+static hipError_t fused_init_ab() {
     hipError_t e = opt_in(dec_fa_kernel<R, true>, FaLds<R>::total * 4);
     if (e == hipSuccess) e = opt_in(dec_fa_kernel<R, false>, FaLds<R>::total * 4);
     if (e == hipSuccess) e = opt_in(dec_fb_kernel<R>, FbLds<R>::total * 4);
-    if (e == hipSuccess) e = opt_in(dec_fc_kernel<R>, FcLds<R>::total * 4);
     return e;
 }
 
 // once per device (engine creation; never inside a stream capture): every instantiation opts in to its LDS size
 hipError_t dec_fused_init() {
-    hipError_t e = fused_init_r<4>();
-    if (e == hipSuccess) e = fused_init_r<8>();
-    if (e == hipSuccess) e = fused_init_r<16>();
+    hipError_t e = fused_init_ab<2>();
+    if (e == hipSuccess) e = fused_init_ab<4>();
+    if (e == hipSuccess) e = opt_in(dec_fc_kernel<4>, FcLds<4>::total * 4);
+    if (e == hipSuccess) e = opt_in(dec_fc_kernel<8>, FcLds<8>::total * 4);
+    if (e == hipSuccess) e = opt_in(dec_fc_kernel<16>, FcLds<16>::total * 4);
     return e;
 }
 
-template <int R>
+// R: rows per workgroup of the two attention stages (256 threads per row); RC: rows per workgroup of the feed-forward stage
+template <int R, int RC>
 static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hipStream_t s) {
     const int D = 256, H = w.heads, T = b.T;
-    const dim3 blk(256);
     int stage = 0;      // stage k reads stream k & 1 and partial buffer (k - 1) & 1, writes stream / partials (k + 1) & 1 / k & 1
     float* xb[2] = {b.x, b.x2};
     float* pb[2] = {b.fpart, b.fpart + (size_t)16 * b.slots * D};
@@ -556,33 +622,38 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hip
         a.gamma = Lw.ln1_g; a.beta = Lw.ln1_b; a.wqkv = Lw.wqkv; a.bqkv = Lw.bqkv; a.wo = Lw.wo;
         a.kcache = b.self_k + (size_t)l * b.slots * H * T * 32;
         a.vcache = b.self_v + (size_t)l * b.slots * H * T * 32;
-        if (l == 0) hipLaunchKernelGGL((dec_fa_kernel<R, true>), dim3(H, rows / R), blk, FaLds<R>::total * 4, s, a);
-        else hipLaunchKernelGGL((dec_fa_kernel<R, false>), dim3(H, rows / R), blk, FaLds<R>::total * 4, s, a);
+        if (l == 0) hipLaunchKernelGGL((dec_fa_kernel<R, true>), dim3(H, rows / R), dim3(256 * R), FaLds<R>::total * 4, s, a);
+        else hipLaunchKernelGGL((dec_fa_kernel<R, false>), dim3(H, rows / R), dim3(256 * R), FaLds<R>::total * 4, s, a);
         ++stage;
         // ---- context-attention block
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = Lw.bo; a.gamma = Lw.ln2_g; a.beta = Lw.ln2_b; a.wq2 = Lw.wq2; a.bq2 = Lw.bq2; a.wo2 = Lw.wo2;
         a.memk = b.mem_kv + (size_t)l * 2 * b.S * D;
-        hipLaunchKernelGGL((dec_fb_kernel<R>), dim3(H, rows / R), blk, FbLds<R>::total * 4, s, a);
+        hipLaunchKernelGGL((dec_fb_kernel<R>), dim3(H, rows / R), dim3(256 * R), FbLds<R>::total * 4, s, a);
         ++stage;
         // ---- feed-forward block
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = Lw.bo2; a.gamma = Lw.lnf_g; a.beta = Lw.lnf_b; a.w1 = Lw.w1; a.b1 = Lw.b1; a.w2 = Lw.w2;
-        hipLaunchKernelGGL((dec_fc_kernel<R>), dim3(w.dff / FF_SLICE, rows / R), blk, FcLds<R>::total * 4, s, a);
+        hipLaunchKernelGGL((dec_fc_kernel<RC>), dim3(w.dff / FF_SLICE, rows / RC), dim3(256), FcLds<RC>::total * 4, s, a);
         ++stage;
     }
 }
 
-// The 3 x layers kernels of a greedy tick for `rows` rows of capacity (a multiple of 32). Returns the stream buffer and
-// the partial buffer the head has to sum (16 partials of the last w_2 + its bias).
+// The 3 x layers kernels of a greedy tick for `rows` rows of capacity (a multiple of 32). row_tile = 10 * R + log2(RC)...:
+// encoded as R * 100 + RC (R in {2, 4}: rows per attention workgroup; RC in {4, 8, 16}: rows per feed-forward workgroup).
+// Returns the stream buffer and the partial buffer the head has to sum (16 partials of the last w_2 + its bias).
 hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int rows, int row_tile, hipStream_t s,
                                     const float** x_final, const float** part_final) {
     if (w.dff != 16 * FF_SLICE || w.heads != 8 || b.T + 1 > PS_SELF || b.S > PS_CROSS || (rows % 16) || !b.fpart)
         return hipErrorInvalidValue;
-    if (row_tile == 4) fused_layers<4>(w, b, rows, s);
-    else if (row_tile == 8) fused_layers<8>(w, b, rows, s);
-    else if (row_tile == 16) fused_layers<16>(w, b, rows, s);
-    else return hipErrorInvalidValue;
+    switch (row_tile) {
+        case 204: fused_layers<2, 4>(w, b, rows, s); break;
+        case 208: fused_layers<2, 8>(w, b, rows, s); break;
+        case 404: fused_layers<4, 4>(w, b, rows, s); break;
+        case 408: fused_layers<4, 8>(w, b, rows, s); break;
+        case 416: fused_layers<4, 16>(w, b, rows, s); break;
+        default: return hipErrorInvalidValue;
+    }
     const int stages = 3 * w.layers;
     *x_final = (stages & 1) ? b.x2 : b.x;
     *part_final = b.fpart + (size_t)((stages - 1) & 1) * 16 * b.slots * 256;

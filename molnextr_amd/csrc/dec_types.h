@@ -110,8 +110,8 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s);
 hipError_t dec_enqueue_status(const DecBuffers& b, int slots, hipStream_t s);
 // forced: [trace_rows, T] ids or null — teacher forcing of slots 0..trace_rows-1 (test aid, see HeadArgs)
-// fused_tile: 0 = the 8-launches-per-layer tick of decoder.hip (always used by beam search); 4 / 8 / 16 = the three-launches-
-// per-layer tick of dec_fused.hip with that many rows per workgroup
+// fused_tile: 0 = the 8-launches-per-layer tick of decoder.hip (always used by beam search); 100 R + RC = the three-launches-
+// per-layer tick of dec_fused.hip with R (2, 4) rows per attention workgroup and RC (4, 8, 16) rows per feed-forward workgroup
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
                             int trace_rows, hipStream_t s, const BeamBuffers* beam = nullptr, const int* forced = nullptr,
                             int fused_tile = 0);

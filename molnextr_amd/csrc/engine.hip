@@ -93,9 +93,10 @@ struct mnx_engine {
     bool have_tc = false;
     int n_chunk_bufs = 0;
     bool use_graph = true;
-    // greedy ticks of up to dec_fused_max rows run as three launches per layer (dec_fused.hip) on row tiles of dec_tile rows;
-    // larger ones keep the 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_FUSED_MAX)
-    int dec_tile = 4, dec_fused_max = 256, dec_tile_big = 0;
+    // greedy ticks of up to dec_fused_max rows run as three launches per layer (dec_fused.hip): dec_tile rows per workgroup in
+    // the two attention stages (256 threads per row), dec_tile_ff rows in the feed-forward stage; larger ticks keep the
+    // 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_TILE_FF, MNX_DEC_FUSED_MAX)
+    int dec_tile = 4, dec_tile_ff = 4, dec_fused_max = 128;
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
     // profiling (bench aid)
     bool profiling = false;
@@ -298,14 +299,14 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
     if (const char* e = getenv("MNX_DEC_TILE")) h->dec_tile = atoi(e);              // 0: never use the fused tick
-    if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity on row tiles of dec_tile
-    if (const char* e = getenv("MNX_DEC_TILE_BIG")) h->dec_tile_big = atoi(e);      // row tile beyond that (0: decoder.hip's tick)
-    for (int* t : {&h->dec_tile, &h->dec_tile_big})
-        if (*t != 0 && *t != 4 && *t != 8 && *t != 16) {
-            g_create_error = "mnx_create: MNX_DEC_TILE / MNX_DEC_TILE_BIG must be 0, 4, 8 or 16";
-            delete h;
-            return MNX_ERR_INVALID_ARG;
-        }
+    if (const char* e = getenv("MNX_DEC_TILE_FF")) h->dec_tile_ff = atoi(e);
+    if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity that runs fused
+    if ((h->dec_tile != 0 && h->dec_tile != 2 && h->dec_tile != 4) ||
+        (h->dec_tile_ff != 4 && h->dec_tile_ff != 8 && h->dec_tile_ff != 16)) {
+        g_create_error = "mnx_create: MNX_DEC_TILE must be 0, 2 or 4 and MNX_DEC_TILE_FF 4, 8 or 16";
+        delete h;
+        return MNX_ERR_INVALID_ARG;
+    }
     Packer P;
     P.h = h;
     for (int i = 0; i < n_weights; ++i)
@@ -708,12 +709,13 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     return MNX_OK;
 }
 
-// row tile of the fused greedy tick for a capacity of `rows` rows (0: the decoder.hip tick)
+// row tiles of the fused greedy tick for a capacity of `rows` rows: 100 x attention tile + feed-forward tile (0: the
+// decoder.hip tick)
 static int tick_tile(const mnx_engine* h, int rows) {
     const mnx_config& c = h->cfg;
     if (c.dec_ff != 1024 || c.dec_heads != 8 || c.dec_dim != 256 || c.max_len + 1 > 512 || h->db.S > 160) return 0;
-    const int t = rows <= h->dec_fused_max ? h->dec_tile : h->dec_tile_big;
-    return (t > 0 && rows % t == 0) ? t : 0;
+    if (h->dec_tile == 0 || rows > h->dec_fused_max || rows % 16) return 0;
+    return 100 * h->dec_tile + h->dec_tile_ff;
 }
 
 static int get_tick_graph(mnx_engine* h, int slots, int rows, float* trace, int trace_rows, hipStream_t s,

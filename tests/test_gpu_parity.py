@@ -310,10 +310,10 @@ def test_beam1_equals_greedy(eng, dev):
         assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
 
 
-def _engine_with_tick(synth_ckpt, tile, fused_max=256, tile_big=0, slots=128):
-    """An engine whose greedy tick runs on the given row tile (0: the 8-launches-per-layer tick of decoder.hip)."""
+def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128):
+    """An engine whose greedy tick runs fused on the given row tiles (tile 0: the 8-launches-per-layer tick of decoder.hip)."""
     from molnextr_amd.engine import Engine
-    keys = {"MNX_DEC_TILE": str(tile), "MNX_DEC_FUSED_MAX": str(fused_max), "MNX_DEC_TILE_BIG": str(tile_big)}
+    keys = {"MNX_DEC_TILE": str(tile), "MNX_DEC_TILE_FF": str(tile_ff), "MNX_DEC_FUSED_MAX": str(fused_max)}
     old = {k: os.environ.get(k) for k in keys}
     os.environ.update(keys)
     try:
@@ -326,29 +326,29 @@ def _engine_with_tick(synth_ckpt, tile, fused_max=256, tile_big=0, slots=128):
                 os.environ[k] = v
 
 
-def test_fused_tick_is_independent_of_the_row_tile_and_matches_the_unfused_tick(eng, dev, synth_ckpt):
-    """dec_fused.hip defines its arithmetic per element (fixed chains, fixed trees), not per thread mapping: row tiles of
-    4, 8 and 16 rows must give BIT-identical hidden states and log-probs; the 8-launches-per-layer tick of decoder.hip sums
-    the same products in another order: same tokens, hidden within 1e-4. Rows finish at different steps (compaction, PE
-    quirk) and run up to position 479 (every prefetch / loop split of the attention)."""
+def test_fused_tick_is_independent_of_the_row_tiles_and_matches_the_unfused_tick(eng, dev, synth_ckpt):
+    """dec_fused.hip defines its arithmetic per element (fixed chains, fixed trees), not per workgroup shape: 2 or 4 rows per
+    attention workgroup, 4 / 8 / 16 rows per feed-forward workgroup must give BIT-identical hidden states and log-probs; the
+    8-launches-per-layer tick of decoder.hip sums the same products in another order: same tokens, hidden within 1e-4. Rows
+    finish at different steps (compaction, PE quirk) and run up to position 479 (second key per thread, value loop tail)."""
     feats = eng.encode(W.synthetic_images(32).to(dev))
     outs = {}
-    for tile in (4, 8, 16, 0):
-        e = _engine_with_tick(synth_ckpt, tile)
+    for tiles in ((4, 4), (2, 8), (4, 16), (0, 4)):
+        e = _engine_with_tick(synth_ckpt, *tiles)
         try:
             a = e.decode_greedy(feats)
             b = e.decode_greedy(feats[:5].contiguous(), max_len=480, stop_on_eos=False)
-            outs[tile] = tuple({k: v.cpu() for k, v in o.items() if v is not None} for o in (a, b))
+            outs[tiles] = tuple({k: v.cpu() for k, v in o.items() if v is not None} for o in (a, b))
         finally:
             e.close()
-    for tile in (8, 16):
-        for x, y in zip(outs[4], outs[tile]):
-            assert torch.equal(x["lengths"], y["lengths"]), f"tile {tile}"
+    for tiles in ((2, 8), (4, 16)):
+        for x, y in zip(outs[(4, 4)], outs[tiles]):
+            assert torch.equal(x["lengths"], y["lengths"]), f"tiles {tiles}"
             for i, n in enumerate(x["lengths"].tolist()):
-                assert torch.equal(x["tokens"][i, :n], y["tokens"][i, :n]), f"tile {tile} row {i}"
-                assert torch.equal(x["hidden"][i, :n], y["hidden"][i, :n]), f"tile {tile} row {i}: hidden states differ bitwise"
-                assert torch.equal(x["token_logp"][i, :n], y["token_logp"][i, :n]), f"tile {tile} row {i}"
-    for x, y in zip(outs[4], outs[0]):
+                assert torch.equal(x["tokens"][i, :n], y["tokens"][i, :n]), f"tiles {tiles} row {i}"
+                assert torch.equal(x["hidden"][i, :n], y["hidden"][i, :n]), f"tiles {tiles} row {i}: hidden states differ bitwise"
+                assert torch.equal(x["token_logp"][i, :n], y["token_logp"][i, :n]), f"tiles {tiles} row {i}"
+    for x, y in zip(outs[(4, 4)], outs[(0, 4)]):
         assert torch.equal(x["lengths"], y["lengths"])
         for i, n in enumerate(x["lengths"].tolist()):
             assert torch.equal(x["tokens"][i, :n], y["tokens"][i, :n]), f"row {i}"
@@ -361,8 +361,8 @@ def test_fused_and_unfused_ticks_mix_in_one_job(eng, dev, synth_ckpt):
     (capacity 192) and drains on the fused one. Tokens / atoms / bonds must equal the all-fused and the all-unfused job."""
     imgs = W.synthetic_images(160, first_index=500).to(dev)
     res = []
-    for tile, fmax, big in ((4, 64, 0), (4, 4096, 0), (0, 0, 0), (4, 64, 16)):
-        e = _engine_with_tick(synth_ckpt, tile, fmax, big, slots=256)
+    for tile, fmax in ((4, 64), (4, 4096), (0, 0), (2, 128)):
+        e = _engine_with_tick(synth_ckpt, tile, 4, fmax, slots=256)
         try:
             res.append({k: v.cpu() for k, v in e.predict(imgs, ref_batch=32).items()})
         finally:

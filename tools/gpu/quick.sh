@@ -17,20 +17,19 @@ except Exception as e:
     print("$n FAILED", e)
 PY
 }
-run fused4_256 MNX_DEC_TILE=4
+run f4_128 MNX_DEC_TILE=4
 run unfused MNX_DEC_TILE=0
-run fused4_256b MNX_DEC_TILE=4
+run f4_128b MNX_DEC_TILE=4
 run unfused_b MNX_DEC_TILE=0
-run fused4_128 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=128
-run fused4_512 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=512
-run fused4_all MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=4096
-run fused8_512 MNX_DEC_TILE=8 MNX_DEC_FUSED_MAX=512
-run fused4_256_big16 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=256 MNX_DEC_TILE_BIG=16
-run fused4_128_big8 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=128 MNX_DEC_TILE_BIG=8
+run f4_256 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=256
+run f4_512 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=512
+run f2_128 MNX_DEC_TILE=2
+run f2_64_ff8 MNX_DEC_TILE=2 MNX_DEC_FUSED_MAX=64 MNX_DEC_TILE_FF=8
+run f4_256_ff8 MNX_DEC_TILE=4 MNX_DEC_FUSED_MAX=256 MNX_DEC_TILE_FF=8
 # tick profile of the "everything fused, tile 4" and default configs
-for cfg in "all MNX_DEC_FUSED_MAX=4096" "def MNX_DEC_FUSED_MAX=256" "big16 MNX_DEC_TILE_BIG=16"; do
+for cfg in "all4 MNX_DEC_FUSED_MAX=4096" "all2 MNX_DEC_TILE=2,MNX_DEC_FUSED_MAX=4096"; do
   set -- $cfg
-  (cd /tmp && env $2 timeout 400 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tick_$1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sub > $GRAFT_REPO_ROOT/gpurun_out/prof_tick_$1.log 2>&1)
+  (cd /tmp && env ${2//,/ } timeout 400 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tick_$1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sub > $GRAFT_REPO_ROOT/gpurun_out/prof_tick_$1.log 2>&1)
   DB=$(find gpurun_out/prof_tick_$1 -name "*.db" | head -1)
   python tools/tick_profile.py $DB gpurun_out/tick_profile_$1.txt | head -12
   rm -f $DB
