@@ -30,15 +30,19 @@
 //
 // All matrix work is v_mfma_f32_16x16x4_f32 (exact fp32 chains); with R < 16 the spare rows of the 16-row tile repeat
 // rows 0..R-1 and are dropped.
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
 #include "common.h"
 #include "kernels.h"
 #include "dec_types.h"
 
 namespace mnx {
 
-constexpr int FXS = 264;    // LDS row stride (floats) of 256-wide rows; strides = 8 (mod 32) make the 16-lane groups of a
-constexpr int FHS = 40;     // ds_read_b128 fragment read hit 64 distinct banks (32-wide rows)
-constexpr int FFS = 72;     // (64-wide rows)
+constexpr int FXS = 260;    // LDS row stride (floats) of 256-wide rows: with strides = 4 (mod 32) the lane-per-row ds_read_b128
+constexpr int FHS = 36;     // of the 4x4x1 MFMA's B operand (lane l reads row n0 + l) hits 64 distinct banks per 16-lane group
+constexpr int FFS = 68;     // (32-wide rows; 64-wide rows)
 constexpr int PS_SELF = 512, PS_CROSS = 160;     // score row length (floats): T <= 511 keys, 144 memory rows
 constexpr float QSCALE = 0.17677669529663687f;   // 1 / sqrt(32): onmt scales the query before QK^T
 constexpr int FF_SLICE = 64;                      // hidden units per dec_fc workgroup
@@ -65,7 +69,22 @@ struct FusedArgs {
     const float *w1, *b1, *w2;
     int dff;
     int T, heads;
+    // lab aid (MNX_FUSED_STAMPS=<file>): [stage][block][phase] 100 MHz wall-clock stamps of the LAST tick, see tools/fused_stamps.py
+    unsigned long long* stamps;
+    int stage;
 };
+constexpr int STAMP_BLOCKS = 512, STAMP_PHASES = 12;
+#ifdef MNX_FUSED_STAMPS     // lab build only (make STAMPS=1): the stamps cost registers in kernels that have none to spare
+#define FSTAMP(ph)                                                                                                        \
+    do {                                                                                                                  \
+        if (a.stamps && threadIdx.x == 0) {                                                                               \
+            const int bid_ = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
+            if (bid_ < STAMP_BLOCKS) a.stamps[((size_t)a.stage * STAMP_BLOCKS + bid_) * STAMP_PHASES + (ph)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                                 \
+    } while (0)
+#else
+#define FSTAMP(ph) do { } while (0)
+#endif
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
 
@@ -134,38 +153,55 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int
 
 // The same for the kernels with 256 threads per row: the four waves of a row share the partial planes (wave rw sums the
 // index block [rw NP / 4, (rw + 1) NP / 4) pairwise = one subtree of the SAME tree), the subtrees meet in LDS (`psum`
-// [R][4][256]) and the row's first wave finishes the sum, writes the stream and normalises. One workgroup barrier inside.
+// [R][4][256]) and the row's first wave finishes the sum, writes the stream and normalises. In two halves, so that a kernel
+// can put its other requests (weights, K / V rows) BEHIND these loads: a wave's loads return in order, whatever is
+// requested first is waited for first.
+template <int NP>
+struct ProRegs {
+    f32x4 x, g, be, bi;
+    f32x4 p[NP >= 4 ? NP / 4 : 1];
+};
 template <int R, int NP, bool EMB>
-__device__ __forceinline__ void fused_prologue_row4(const FusedArgs& a, int row0, int n_act, bool writer, float* xs, float* psum) {
+__device__ __forceinline__ void prologue_issue(const FusedArgs& a, int row0, ProRegs<NP>& pr) {
     const int lane = threadIdx.x & 63, rl = threadIdx.x >> 8, rw = (threadIdx.x >> 6) & 3;
     const int row = row0 + rl;
-    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    pr.x = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (EMB) {
         if (rw == 0) {
             // x0 = E[tok] * sqrt(256) + pe[rank]   (reference components.py:290, embedding.py:52-59)
             const int4 rv = a.st->rowv[row];
-            x = ldg4(a.emb + (size_t)rv.z * 256 + lane * 4) * 16.0f + ldg4(a.pe + (size_t)rv.w * 256 + lane * 4);
+            pr.x = ldg4(a.emb + (size_t)rv.z * 256 + lane * 4) * 16.0f + ldg4(a.pe + (size_t)rv.w * 256 + lane * 4);
         }
     } else {
         constexpr int Q = NP >= 4 ? NP / 4 : 1;
-        f32x4 p[Q];
 #pragma unroll
-        for (int z = 0; z < Q; ++z) p[z] = ldg4(a.part_in + (size_t)(rw * Q + z) * a.part_stride + (size_t)row * 256 + lane * 4);
-        if (rw == 0) x = ldg4(a.xin + (size_t)row * 256 + lane * 4);
-        *(f32x4*)(psum + (rl * 4 + rw) * 256 + lane * 4) = tree_sum<Q>(p);
+        for (int z = 0; z < Q; ++z) pr.p[z] = ldg4(a.part_in + (size_t)(rw * Q + z) * a.part_stride + (size_t)row * 256 + lane * 4);
+        if (rw == 0) pr.x = ldg4(a.xin + (size_t)row * 256 + lane * 4);
     }
+    pr.g = ldg4(a.gamma + lane * 4);
+    pr.be = ldg4(a.beta + lane * 4);
+    pr.bi = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!EMB) pr.bi = ldg4(a.bias_in + lane * 4);
+}
+template <int R, int NP, bool EMB>
+__device__ __forceinline__ void prologue_finish(const FusedArgs& a, int row0, int n_act, bool writer, float* xs, float* psum,
+                                                ProRegs<NP>& pr) {
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 8, rw = (threadIdx.x >> 6) & 3;
+    const int row = row0 + rl;
+    if (!EMB) *(f32x4*)(psum + (rl * 4 + rw) * 256 + lane * 4) = tree_sum<(NP >= 4 ? NP / 4 : 1)>(pr.p);
     __syncthreads();
     if (rw != 0) return;
+    f32x4 x = pr.x;
     if (!EMB) {
         const float* pp = psum + rl * 1024 + lane * 4;
         const f32x4 t = (*(const f32x4*)pp + *(const f32x4*)(pp + 256)) + (*(const f32x4*)(pp + 512) + *(const f32x4*)(pp + 768));
-        x = x + (t + ldg4(a.bias_in + lane * 4));
+        x = x + (t + pr.bi);
     }
     if (writer && row < n_act) *(f32x4*)(a.xout + (size_t)row * 256 + lane * 4) = x;
     const float mean = wave_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 256.0f);
     x -= mean;
     const float var = wave_sum((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) * (1.0f / 256.0f);
-    *(f32x4*)(xs + rl * FXS + lane * 4) = x * rsqrtf(var + 1e-6f) * ldg4(a.gamma + lane * 4) + ldg4(a.beta + lane * 4);
+    *(f32x4*)(xs + rl * FXS + lane * 4) = x * rsqrtf(var + 1e-6f) * pr.g + pr.be;
 }
 
 // ---- NROWS weight rows x 256 k (blocks of 32 consecutive rows of W, block b starting at rowbase[b]) -> registers -> LDS
@@ -202,49 +238,56 @@ __device__ __forceinline__ void wstore256(const WRegs<NROWS, NW>& w, float* ws) 
     }
 }
 
-// ---- out[r][c] = xs[r][:] . ws[c][:] over K = 256 as FOUR chains: chain kq multiplies k in [64 kq, 64 kq + 64) as 16 MFMA
-// k-steps (k-slot g of step j of chunk kc <-> k = 64 kq + 16 kc + 4 g + j on both operands); the chains meet in `red`.
-// Wave w computes chain w & 3 of the n-tiles of group w >> 2 (NW / 4 groups share the NT tiles).
-template <int NT, int NW> struct TileGroup { static constexpr int TPG = (NT + NW / 4 - 1) / (NW / 4); };
-template <int NT, int R, int NW>
-__device__ __forceinline__ void mfma_k256(const float* xs, const float* ws, f32x4 (&acc)[TileGroup<NT, NW>::TPG]) {
-    constexpr int TPG = TileGroup<NT, NW>::TPG;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-    const int kq = wave & 3, t0 = (wave >> 2) * TPG;
+// ---- the 4-row matrix instruction: v_mfma_f32_4x4x1_16B_f32 = 16 independent 4x4 outer products. Lane l supplies
+// A = x[row l & 3][k] (every block gets the same four rows) and B = W[n0 + l][k]; accumulator register i of lane l is
+// out[row i][n0 + l]: one instruction multiplies 4 rows by 64 columns for ONE k, at a quarter of the 16x16x4 cost per row
+// tile — the decode tick's row tiles are 2-4 rows, a 16-row MFMA tile would be 3/4 padding. A chain over k is a
+// sequential exact-fp32 fmaf chain in program order: the same numbers whatever the row tile.
+// x: LDS [R][XSTR] (+ k offset), wrow: this lane's weight row in LDS (+ k offset); rows beyond R repeat rows 0..R-1.
+template <int R, int XSTR>
+__device__ __forceinline__ void chain4(const float* x, const float* wrow, int nk, f32x4 (&acc)[(R + 3) / 4]) {
+    constexpr int NRG = (R + 3) / 4;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + ((lane & 3) & (R - 1)) * XSTR;
 #pragma unroll
-    for (int n = 0; n < TPG; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (t0 >= NT) return;
+    for (int g = 0; g < NRG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < nk; k += 4) {
+        const f32x4 b4 = *(const f32x4*)(wrow + k);
+        f32x4 a4[NRG];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-        const int kb = kq * 64 + kc * 16 + fg * 4;
-        const f32x4 av = *(const f32x4*)(xs + (fr & (R - 1)) * FXS + kb);
-        f32x4 bv[TPG];
+        for (int g = 0; g < NRG; ++g) a4[g] = *(const f32x4*)(xr + g * 4 * XSTR + k);
 #pragma unroll
-        for (int n = 0; n < TPG; ++n) bv[n] = *(const f32x4*)(ws + (16 * min(t0 + n, NT - 1) + fr) * FXS + kb);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int n = 0; n < TPG; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[n][j], acc[n], 0, 0, 0);
+            for (int g = 0; g < NRG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g][e], b4[e], acc[g], 0, 0, 0);
     }
 }
-// D layout: lane (fr, fg) holds rows 4 fg + i, column fr of every n-tile
-template <int NT, int R, int NW>
-__device__ __forceinline__ void red_store(const f32x4 (&acc)[TileGroup<NT, NW>::TPG], float* red) {
-    constexpr int TPG = TileGroup<NT, NW>::TPG;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-    const int kq = wave & 3, t0 = (wave >> 2) * TPG;
-    constexpr int RS = NT * 16 + 4;
-#pragma unroll
-    for (int n = 0; n < TPG; ++n)
-        if (t0 + n < NT) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (fg * 4 + i < R) red[(kq * R + fg * 4 + i) * RS + (t0 + n) * 16 + fr] = acc[n][i];
-        }
+
+// ---- out[r][c] = xs[r][:] . ws[c][:] over K = 256 as FOUR chains (chain kq: k = 64 kq .. 64 kq + 63 ascending), combined
+// (c0 + c1) + (c2 + c3) through `red`. Unit (column block cb of 64, chain kq) runs on wave kq + 4 cb.
+template <int NCOL, int R>
+__device__ __forceinline__ void lin256_mfma(const float* xs, const float* ws, f32x4 (&acc)[(R + 3) / 4]) {
+    constexpr int NCB = (NCOL + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= 4 * NCB) return;
+    const int kq = wave & 3, n = min((wave >> 2) * 64 + lane, NCOL - 1);
+    chain4<R, FXS>(xs + 64 * kq, ws + n * FXS + 64 * kq, 64, acc);
 }
-template <int NT, int R>
+template <int NCOL, int R>
+__device__ __forceinline__ void lin256_red(const f32x4 (&acc)[(R + 3) / 4], float* red) {
+    constexpr int NCB = (NCOL + 63) / 64, RS = NCOL + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= 4 * NCB) return;
+    const int kq = wave & 3, n = (wave >> 2) * 64 + lane;
+    if (n < NCOL) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) red[(kq * R + i) * RS + n] = acc[i >> 2][i & 3];
+    }
+}
+template <int NCOL, int R>
 __device__ __forceinline__ float red_get(const float* red, int r, int c) {
-    constexpr int RS = NT * 16 + 4;
+    constexpr int RS = NCOL + 4;
     return (red[(0 * R + r) * RS + c] + red[(1 * R + r) * RS + c]) + (red[(2 * R + r) * RS + c] + red[(3 * R + r) * RS + c]);
 }
 
@@ -271,36 +314,18 @@ __device__ __forceinline__ void sstore(const SliceRegs<KW, NW>& s, float* dst) {
     for (int j = 0; j < S::NPASS; ++j) *(f32x4*)(dst + (n0 + S::RPI * j) * STR + c4 * 4) = s.v[j];
 }
 
-// ---- partial[row][n] = sum_{k < KW} in[r][k] * wsl[n][k] (ONE chain of KW / 4 MFMA k-steps per element): the 16 n-tiles are
-// spread over the NW waves ----
-template <int KW, int STR, int R, int NW>
-__device__ __forceinline__ void mfma_slice_store(const float* in /*[R][STR]*/, const float* wsl /*[256][STR]*/, float* out,
+// ---- partial[row][n] = sum_{k < KW} in[r][k] * wsl[n][k], ONE chain (k ascending) per element: wave cb < 4 owns columns
+// [64 cb, 64 cb + 64) ----
+template <int KW, int STR, int R>
+__device__ __forceinline__ void slice_mfma_store(const float* in /*[R][STR]*/, const float* wsl /*[256][STR]*/, float* out,
                                                  int row0, int n_act) {
-    constexpr int TWV = 16 / NW;     // n-tiles per wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-    f32x4 acc[TWV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= 4) return;
+    f32x4 acc[(R + 3) / 4];
+    chain4<R, STR>(in, wsl + (64 * wave + lane) * STR, KW, acc);
 #pragma unroll
-    for (int n = 0; n < TWV; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < KW / 16; ++kc) {
-        const int kb = kc * 16 + fg * 4;
-        const f32x4 av = *(const f32x4*)(in + (fr & (R - 1)) * STR + kb);
-        f32x4 bv[TWV];
-#pragma unroll
-        for (int n = 0; n < TWV; ++n) bv[n] = *(const f32x4*)(wsl + (16 * (wave * TWV + n) + fr) * STR + kb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int n = 0; n < TWV; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[n][j], acc[n], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + fg * 4 + i;
-        if (fg * 4 + i < R && row < n_act) {
-#pragma unroll
-            for (int n = 0; n < TWV; ++n) out[(size_t)row * 256 + 16 * (wave * TWV + n) + fr] = acc[n][i];
-        }
-    }
+    for (int i = 0; i < R; ++i)
+        if (row0 + i < n_act) out[(size_t)(row0 + i) * 256 + 64 * wave + lane] = acc[i >> 2][i & 3];
 }
 
 // ---- single-query attention of one head for R rows, 256 threads (4 waves) per row — the arithmetic of round 3's
@@ -319,12 +344,16 @@ struct AttnPre {
 };
 
 template <int VP>
-__device__ __forceinline__ void attn_prefetch(AttnPre<VP>& pre, const float* Kb, const float* Vb, int ncache) {
-    const int rt = threadIdx.x & 255, rw = rt >> 6, kg = (rt & 63) >> 3, dq = rt & 7;
-    const int last = ncache > 0 ? ncache - 1 : 0;       // clamped: always a row of the slot's cache, unused beyond ncache
-    const int key = min(rt, last);
+__device__ __forceinline__ void attn_prefetch_k(AttnPre<VP>& pre, const float* Kb, int ncache) {
+    const int rt = threadIdx.x & 255;
+    const int key = min(rt, ncache > 0 ? ncache - 1 : 0);   // clamped: always a row of the slot's cache, unused beyond ncache
 #pragma unroll
     for (int i = 0; i < 8; ++i) pre.k[i] = ldg4(Kb + (size_t)key * 32 + i * 4);
+}
+template <int VP>
+__device__ __forceinline__ void attn_prefetch_v(AttnPre<VP>& pre, const float* Vb, int ncache) {
+    const int rt = threadIdx.x & 255, rw = rt >> 6, kg = (rt & 63) >> 3, dq = rt & 7;
+    const int last = ncache > 0 ? ncache - 1 : 0;
 #pragma unroll
     for (int i = 0; i < VP; ++i) pre.v[i] = ldg4(Vb + (size_t)min(rw * 8 + kg + 32 * i, last) * 32 + dq * 4);
 }
@@ -332,7 +361,8 @@ __device__ __forceinline__ void attn_prefetch(AttnPre<VP>& pre, const float* Kb,
 struct AttnLds { float *qs, *ks, *vs, *ps, *cs, *redm, *reds, *po; };   // per-kernel LDS arrays, all [R][...]
 
 template <int R, bool CROSS, int VP, int PS>
-__device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* Kb, const float* Vb, int ncache, const AttnLds& m) {
+__device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* Kb, const float* Vb, int ncache, const AttnLds& m,
+                                          const FusedArgs& a) {
     const int rl = threadIdx.x >> 8, rt = threadIdx.x & 255, lane = rt & 63, rw = rt >> 6, kg = lane >> 3, dq = lane & 7;
     float* ps = m.ps + rl * PS;
     const int nkeys = CROSS ? ncache : ncache + 1;
@@ -367,6 +397,7 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
     mx = wave_max(mx);
     if (lane == 0) m.redm[rl * 4 + rw] = mx;
     __syncthreads();
+    FSTAMP(7);
     mx = fmaxf(fmaxf(m.redm[rl * 4 + 0], m.redm[rl * 4 + 1]), fmaxf(m.redm[rl * 4 + 2], m.redm[rl * 4 + 3]));
     float sum = 0.f;
 #pragma unroll
@@ -379,6 +410,7 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
     sum = wave_sum(sum);
     if (lane == 0) m.reds[rl * 4 + rw] = sum;
     __syncthreads();
+    FSTAMP(8);
     sum = (m.reds[rl * 4 + 0] + m.reds[rl * 4 + 1]) + (m.reds[rl * 4 + 2] + m.reds[rl * 4 + 3]);
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -412,6 +444,7 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
     }
     if (lane < 8) *(f32x4*)(m.po + (rl * 4 + rw) * 32 + dq * 4) = o;
     __syncthreads();
+    FSTAMP(9);
     if (rt < 8) {
         const float* pp = m.po + rl * 128 + rt * 4;
         const f32x4 r = (*(const f32x4*)pp + *(const f32x4*)(pp + 32)) + (*(const f32x4*)(pp + 64) + *(const f32x4*)(pp + 96));
@@ -426,7 +459,7 @@ template <int R> struct FaLds {
     static constexpr int redm = cs + R * FHS, reds = redm + R * 4, po = reds + R * 4;              // [R][4] x2, [R][4][32]
     static constexpr int psum = po + R * 128;                     // [R][4][256] subtrees of the prologue
     static constexpr int ws = psum + R * 1024;                    // [96][FXS]; after the qkv MFMAs: red | wos | ps
-    static constexpr int red = ws, wos = red + 4 * R * 100, ps = wos + 256 * FHS;
+    static constexpr int red = ws, wos = red + 4 * R * 100, ps = wos + 256 * FHS;   // red [4][R][96 + 4]
     static constexpr int end_a = ws + 96 * FXS, end_b = ps + R * PS_SELF;
     static constexpr int total = end_a > end_b ? end_a : end_b;
 };
@@ -436,14 +469,14 @@ template <int R> struct FbLds {
     static constexpr int psum = po + R * 128;                     // [R][4][256] subtrees of the prologue
     static constexpr int wos = psum + R * 1024;                   // [256][FHS]
     static constexpr int ws = wos + 256 * FHS;                    // [32][FXS]; after the q MFMAs: red | ps
-    static constexpr int red = ws, ps = red + 4 * R * 36;
+    static constexpr int red = ws, ps = red + 4 * R * 36;                          // red [4][R][32 + 4]
     static constexpr int end_a = ws + 32 * FXS, end_b = ps + R * PS_CROSS;
     static constexpr int total = end_a > end_b ? end_a : end_b;
 };
 template <int R> struct FcLds {
     static constexpr int xs = 0, hs = xs + R * FXS;               // hs [R][FFS]
     static constexpr int ws = hs + R * FFS;                       // [64][FXS]; after the w_1 MFMAs: red | w2s [256][FFS]
-    static constexpr int red = ws, w2s = red + 4 * R * 68;
+    static constexpr int red = ws, w2s = red + 4 * R * 68;                         // red [4][R][64 + 4]
     static constexpr int end_a = ws + 64 * FXS, end_b = w2s + 256 * FFS;
     static constexpr int total = end_a > end_b ? end_a : end_b;
 };
@@ -460,30 +493,40 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     constexpr int VP = 8;
     const int tid = threadIdx.x;
     const int h = blockIdx.x, row0 = blockIdx.y * R;
+    FSTAMP(0);
     const int4 rv = a.st->rowv[row0 + (tid >> 8)];       // {slot, t, prev_tok, rank} of the row this thread attends for
     const int n_act = a.st->n_active;
+    // requests in the order of need: stream + partials, the head's qkv rows, this thread's key; the value rows and the
+    // head's slice of Wo once the weights have left their registers
+    ProRegs<EMB ? 0 : 16> pr;
+    prologue_issue<R, EMB ? 0 : 16, EMB>(a, row0, pr);
     WRegs<96, 4 * R> wv;
     const int rb[3] = {32 * h, 256 + 32 * h, 512 + 32 * h};
     wload256<96, 4 * R>(wv, a.wqkv, rb);
-    fused_prologue_row4<R, EMB ? 0 : 16, EMB>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum);
-    wstore256<96, 4 * R>(wv, smem + Ld::ws);
-    // requested now, used after the qkv MFMAs: the head's slice of Wo, this thread's key and its first value rows
     const float* Kb = a.kcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
     const float* Vb = a.vcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
     AttnPre<VP> pre;
-    attn_prefetch<VP>(pre, Kb, Vb, rv.y);
+    attn_prefetch_k<VP>(pre, Kb, rv.y);
+    prologue_finish<R, EMB ? 0 : 16, EMB>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum, pr);
+    FSTAMP(1);
+    wstore256<96, 4 * R>(wv, smem + Ld::ws);
+    FSTAMP(2);
+    attn_prefetch_v<VP>(pre, Vb, rv.y);
     SliceRegs<32, 4 * R> wov;
     sload<32, 4 * R>(wov, a.wo, 256, 32 * h);
     __syncthreads();
-    f32x4 acc[TileGroup<6, 4 * R>::TPG];
-    mfma_k256<6, R, 4 * R>(smem + Ld::xs, smem + Ld::ws, acc);
+    FSTAMP(3);
+    f32x4 acc[1];
+    lin256_mfma<96, R>(smem + Ld::xs, smem + Ld::ws, acc);
     __syncthreads();                                     // every wave is done with ws: it becomes red | wos | ps
-    red_store<6, R, 4 * R>(acc, smem + Ld::red);
+    FSTAMP(4);
+    lin256_red<96, R>(acc, smem + Ld::red);
     sstore<32, FHS, 4 * R>(wov, smem + Ld::wos);
     __syncthreads();
+    FSTAMP(5);
     for (int idx = tid; idx < R * 96; idx += 256 * R) {
         const int r = idx / 96, c = idx - r * 96, part = c >> 5, d = c & 31;
-        const float v = red_get<6, R>(smem + Ld::red, r, c) + a.bqkv[part * 256 + 32 * h + d];
+        const float v = red_get<96, R>(smem + Ld::red, r, c) + a.bqkv[part * 256 + 32 * h + d];
         if (part == 0) {
             smem[Ld::qs + r * 32 + d] = v * QSCALE;
         } else {
@@ -497,11 +540,14 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
         }
     }
     __syncthreads();
+    FSTAMP(6);
     const AttnLds m = {smem + Ld::qs, smem + Ld::ks, smem + Ld::vs, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm,
                        smem + Ld::reds, smem + Ld::po};
-    attn_rows<R, false, VP, PS_SELF>(pre, Kb, Vb, rv.y, m);
+    attn_rows<R, false, VP, PS_SELF>(pre, Kb, Vb, rv.y, m, a);
     __syncthreads();
-    mfma_slice_store<32, FHS, R, 4 * R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    FSTAMP(10);
+    slice_mfma_store<32, FHS, R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    FSTAMP(11);
 }
 
 // =============================================================================================
@@ -515,36 +561,51 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     constexpr int VP = 5;                                // 144 memory rows = 4.5 x 32: every value row is prefetched
     const int tid = threadIdx.x;
     const int h = blockIdx.x, row0 = blockIdx.y * R;
+    FSTAMP(0);
     const int mb = a.st->row_mem[row0 + (tid >> 8)];
     const int n_act = a.st->n_active;
     const float* Kb = a.memk + (size_t)mb * a.mem_stride + (size_t)h * a.S * 32;
     const float* Vb = Kb + (size_t)a.S * 256;
-    AttnPre<VP> pre;
-    attn_prefetch<VP>(pre, Kb, Vb, a.S);               // memory rows: nothing of this tick is needed to ask for them
+    // requests in the order of need: stream + partials, the head's query rows, then the memory rows (nothing of this tick
+    // is needed to ask for them, but whatever is requested first is waited for first)
+    ProRegs<8> pr;
+    prologue_issue<R, 8, false>(a, row0, pr);
     WRegs<32, 4 * R> wv;
     const int rb[1] = {32 * h};
     wload256<32, 4 * R>(wv, a.wq2, rb);
-    fused_prologue_row4<R, 8, false>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum);
+    AttnPre<VP> pre;
+    attn_prefetch_k<VP>(pre, Kb, a.S);
+    if (R < 4) attn_prefetch_v<VP>(pre, Vb, a.S);
+    prologue_finish<R, 8, false>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum, pr);
+    FSTAMP(1);
     wstore256<32, 4 * R>(wv, smem + Ld::ws);
+    FSTAMP(2);
+    if (R >= 4) attn_prefetch_v<VP>(pre, Vb, a.S);      // 1024 threads = 128 registers each: the value rows wait for the weights' registers
     __syncthreads();
+    FSTAMP(3);
     SliceRegs<32, 4 * R> wov;
     sload<32, 4 * R>(wov, a.wo2, 256, 32 * h);
-    f32x4 acc[TileGroup<2, 4 * R>::TPG];
-    mfma_k256<2, R, 4 * R>(smem + Ld::xs, smem + Ld::ws, acc);
+    f32x4 acc[1];
+    lin256_mfma<32, R>(smem + Ld::xs, smem + Ld::ws, acc);
     __syncthreads();
-    red_store<2, R, 4 * R>(acc, smem + Ld::red);
+    FSTAMP(4);
+    lin256_red<32, R>(acc, smem + Ld::red);
     sstore<32, FHS, 4 * R>(wov, smem + Ld::wos);
     __syncthreads();
+    FSTAMP(5);
     for (int idx = tid; idx < R * 32; idx += 256 * R) {
         const int r = idx >> 5, d = idx & 31;
-        smem[Ld::qs + r * 32 + d] = (red_get<2, R>(smem + Ld::red, r, d) + a.bq2[32 * h + d]) * QSCALE;
+        smem[Ld::qs + r * 32 + d] = (red_get<32, R>(smem + Ld::red, r, d) + a.bq2[32 * h + d]) * QSCALE;
     }
     __syncthreads();
+    FSTAMP(6);
     const AttnLds m = {smem + Ld::qs, nullptr, nullptr, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm, smem + Ld::reds,
                        smem + Ld::po};
-    attn_rows<R, true, VP, PS_CROSS>(pre, Kb, Vb, a.S, m);
+    attn_rows<R, true, VP, PS_CROSS>(pre, Kb, Vb, a.S, m, a);
     __syncthreads();
-    mfma_slice_store<32, FHS, R, 4 * R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    FSTAMP(10);
+    slice_mfma_store<32, FHS, R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    FSTAMP(11);
 }
 
 // =============================================================================================
@@ -557,27 +618,35 @@ __global__ __launch_bounds__(256) void dec_fc_kernel(FusedArgs a) {
     typedef FcLds<R> Ld;
     const int tid = threadIdx.x;
     const int sl = blockIdx.x, row0 = blockIdx.y * R;
+    FSTAMP(0);
     const int n_act = a.st->n_active;
     WRegs<64, 4> wv;
     const int rb[2] = {FF_SLICE * sl, FF_SLICE * sl + 32};
     wload256<64, 4>(wv, a.w1, rb);
     fused_prologue<R, 4, 8, false>(a, row0, n_act, sl == 0, smem + Ld::xs);
+    FSTAMP(1);
     wstore256<64, 4>(wv, smem + Ld::ws);
+    FSTAMP(2);
     SliceRegs<64, 4> w2v;
     sload<64, 4>(w2v, a.w2, a.dff, FF_SLICE * sl);
     __syncthreads();
-    f32x4 acc[4];
-    mfma_k256<4, R, 4>(smem + Ld::xs, smem + Ld::ws, acc);
+    FSTAMP(3);
+    f32x4 acc[(R + 3) / 4];
+    lin256_mfma<64, R>(smem + Ld::xs, smem + Ld::ws, acc);
     __syncthreads();
-    red_store<4, R, 4>(acc, smem + Ld::red);
+    FSTAMP(4);
+    lin256_red<64, R>(acc, smem + Ld::red);
     sstore<64, FFS, 4>(w2v, smem + Ld::w2s);
     __syncthreads();
+    FSTAMP(5);
     for (int idx = tid; idx < R * 64; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
-        smem[Ld::hs + r * FFS + c] = gelu_erf(red_get<4, R>(smem + Ld::red, r, c) + a.b1[FF_SLICE * sl + c]);
+        smem[Ld::hs + r * FFS + c] = gelu_erf(red_get<64, R>(smem + Ld::red, r, c) + a.b1[FF_SLICE * sl + c]);
     }
     __syncthreads();
-    mfma_slice_store<64, FFS, R, 4>(smem + Ld::hs, smem + Ld::w2s, a.part_out + (size_t)sl * a.part_stride, row0, n_act);
+    FSTAMP(10);
+    slice_mfma_store<64, FFS, R>(smem + Ld::hs, smem + Ld::w2s, a.part_out + (size_t)sl * a.part_stride, row0, n_act);
+    FSTAMP(11);
 }
 
 // ---- host side -------------------------------------------------------------------------------
@@ -594,8 +663,26 @@ static hipError_t fused_init_ab() {
     return e;
 }
 
+static unsigned long long* g_stamps = nullptr;     // lab aid, see FusedArgs::stamps
+static const size_t STAMP_WORDS = (size_t)3 * MAX_DEC_LAYERS * STAMP_BLOCKS * STAMP_PHASES;
+
+// writes the stamps of the last fused tick to `path` (binary u64 [stages][STAMP_BLOCKS][STAMP_PHASES]); tools/fused_stamps.py
+void dec_fused_dump_stamps(const char* path) {
+    if (!g_stamps || !path) return;
+    std::vector<unsigned long long> host(STAMP_WORDS);
+    if (hipMemcpy(host.data(), g_stamps, STAMP_WORDS * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (FILE* f = fopen(path, "wb")) {
+        fwrite(host.data(), 8, STAMP_WORDS, f);
+        fclose(f);
+    }
+}
+
 // once per device (engine creation; never inside a stream capture): every instantiation opts in to its LDS size
 hipError_t dec_fused_init() {
+    if (getenv("MNX_FUSED_STAMPS") && !g_stamps) {
+        if (hipMalloc((void**)&g_stamps, STAMP_WORDS * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(g_stamps, 0, STAMP_WORDS * 8);
+    }
     hipError_t e = fused_init_ab<2>();
     if (e == hipSuccess) e = fused_init_ab<4>();
     if (e == hipSuccess) e = opt_in(dec_fc_kernel<4>, FcLds<4>::total * 4);
@@ -614,9 +701,11 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hip
     FusedArgs a = {};
     a.st = b.st; a.part_stride = b.slots * D; a.T = T; a.heads = H; a.emb = w.emb; a.pe = w.pe; a.S = b.S; a.dff = w.dff;
     a.mem_stride = (long long)b.S * w.layers * 2 * D;
+    a.stamps = g_stamps;
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& Lw = w.L[l];
         // ---- self-attention block
+        a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = l > 0 ? w.L[l - 1].b2 : nullptr;
         a.gamma = Lw.ln1_g; a.beta = Lw.ln1_b; a.wqkv = Lw.wqkv; a.bqkv = Lw.bqkv; a.wo = Lw.wo;
@@ -626,12 +715,14 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hip
         else hipLaunchKernelGGL((dec_fa_kernel<R, false>), dim3(H, rows / R), dim3(256 * R), FaLds<R>::total * 4, s, a);
         ++stage;
         // ---- context-attention block
+        a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = Lw.bo; a.gamma = Lw.ln2_g; a.beta = Lw.ln2_b; a.wq2 = Lw.wq2; a.bq2 = Lw.bq2; a.wo2 = Lw.wo2;
         a.memk = b.mem_kv + (size_t)l * 2 * b.S * D;
         hipLaunchKernelGGL((dec_fb_kernel<R>), dim3(H, rows / R), dim3(256 * R), FbLds<R>::total * 4, s, a);
         ++stage;
         // ---- feed-forward block
+        a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = Lw.bo2; a.gamma = Lw.lnf_g; a.beta = Lw.lnf_b; a.w1 = Lw.w1; a.b1 = Lw.b1; a.w2 = Lw.w2;
         hipLaunchKernelGGL((dec_fc_kernel<RC>), dim3(w.dff / FF_SLICE, rows / RC), dim3(256), FcLds<RC>::total * 4, s, a);

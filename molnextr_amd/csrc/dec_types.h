@@ -117,6 +117,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
                             int fused_tile = 0);
 // dec_fused.hip
 hipError_t dec_fused_init();
+void dec_fused_dump_stamps(const char* path);   // lab aid (MNX_FUSED_STAMPS)
 hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int rows, int row_tile, hipStream_t s,
                                     const float** x_final, const float** part_final);
 hipError_t beam_enqueue_init(const DecBuffers& b, const BeamBuffers& bm, int max_len, hipStream_t s);

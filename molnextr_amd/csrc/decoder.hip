@@ -517,6 +517,119 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     }
 }
 
+// The head of the fused tick (dec_fused.hip): the same chain for one row on 1024 threads — the output layer's 232 x 256
+// weights (237 KB, what this kernel's time is made of) are requested by four times as many lanes, thread (kq, column)
+// multiplying k in [64 kq, 64 kq + 64) (four interleaved fmaf chains, as dec_head_kernel's), the quarters summed
+// (q0 + q1) + (q2 + q3). Greedy only; everything after the logits is dec_head_kernel's code on the first 256 threads.
+__global__ __launch_bounds__(1024) void dec_head4_kernel(HeadArgs a) {
+    __shared__ float hv[256];
+    __shared__ float lq[4][256];
+    __shared__ float red[8];
+    __shared__ int redi[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = tid & 255, kq = tid >> 8;
+    const int row = blockIdx.x;
+    const int4 rv = a.st->rowv[row];
+    const int n_act = a.st->n_active;
+    const bool valid = col < a.V;
+    // the weights do not depend on the tick: ask for them first (16 per batch, 4 batches)
+    float wk[16];
+    const float* wp = a.wout_t + (size_t)(64 * kq) * a.VP + (valid ? col : 0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wk[k] = wp[(size_t)k * a.VP];
+    if (wave == 0) {
+        const float* pp = a.part + (size_t)row * 256 + lane * 4;
+        const size_t ps = (size_t)a.part_stride;
+        f32x4 p[16];
+#pragma unroll
+        for (int z = 0; z < 16; ++z) p[z] = *(const f32x4*)(pp + z * ps);
+        f32x4 v = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
+#pragma unroll
+        for (int w = 1; w < 16; w *= 2)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2 * w) p[i] += p[i + w];
+        v = v + (p[0] + *(const f32x4*)(a.tree_bias + lane * 4));
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+        v -= mean;
+        const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
+        const f32x4 o = v * rsqrtf(var + 1e-6f) * *(const f32x4*)(a.gamma + lane * 4) + *(const f32x4*)(a.beta + lane * 4);
+        *(f32x4*)(hv + lane * 4) = o;
+        if (row < n_act) *(f32x4*)(a.hidden + ((size_t)rv.x * a.T + rv.y) * 256 + lane * 4) = o;
+    }
+    __syncthreads();
+    {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float* hq = hv + 64 * kq;
+#pragma unroll
+        for (int kb = 0; kb < 64; kb += 16) {
+            float wn[16];
+            if (kb + 16 < 64) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wn[k] = wp[(size_t)(kb + 16 + k) * a.VP];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                s0 = fmaf(hq[kb + k], wk[k], s0);
+                s1 = fmaf(hq[kb + k + 1], wk[k + 1], s1);
+                s2 = fmaf(hq[kb + k + 2], wk[k + 2], s2);
+                s3 = fmaf(hq[kb + k + 3], wk[k + 3], s3);
+            }
+            if (kb + 16 < 64) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wk[k] = wn[k];
+            }
+        }
+        lq[kq][col] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (row >= n_act) return;
+    const int slot = rv.x, t = rv.y;
+    float logit = -3.0e38f;
+    if (tid < 256 && valid) {
+        logit = ((lq[0][col] + lq[1][col]) + (lq[2][col] + lq[3][col])) + a.bout[col];
+        if (a.logits_trace && slot < a.trace_rows) a.logits_trace[((size_t)t * a.trace_rows + slot) * a.V + col] = logit;
+    }
+    // log_softmax (the first four waves hold the 232 logits, the others contribute neutral elements)
+    float m = wave_max(logit);
+    if (lane == 0 && wave < 4) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float e = (tid < 256 && valid) ? expf(logit - m) : 0.f;
+    e = wave_sum(e);
+    if (lane == 0 && wave < 4) red[4 + wave] = e;
+    __syncthreads();
+    const float lse = m + logf(red[4] + red[5] + red[6] + red[7]);
+    float lp = logit - lse;
+    const int prev = rv.z;
+    if (prev >= a.x0 && prev < a.y0) { if (col < a.y0) lp = -10000.0f; }     // after an x-bin: only y-bins
+    else if (prev >= a.y0)           { if (col >= a.x0) lp = -10000.0f; }    // after a y-bin: no coordinate bins
+    if (t == 0 && col == a.eos) lp = -1e20f;                                  // min_length = 1
+    if (!(tid < 256 && valid)) lp = -3.0e38f;
+    // argmax, lowest index wins ties (topk(1)); threads beyond the first 256 carry neutral elements
+    float bv = lp;
+    int bi = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0 && wave < 4) { red[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    const int ftok = (a.forced && slot < a.trace_rows) ? a.forced[(size_t)slot * a.T + t] : -1;
+    if (ftok >= 0 && tid == ftok) a.token_logp[(size_t)slot * a.T + t] = lp;
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
+        a.tokens[(size_t)slot * a.T + t] = bi;
+        if (ftok < 0) a.token_logp[(size_t)slot * a.T + t] = bv;
+        const int adv = ftok >= 0 ? ftok : bi;
+        a.st->prev_tok[slot] = adv;
+        a.st->len[slot] = t + 1;
+        a.st->t[slot] = t + 1;
+        if ((a.st->stop_on_eos[slot] && adv == a.eos) || t + 1 >= a.st->max_len[slot]) a.st->alive[slot] = 0;
+    }
+}
+
 // Opens a tick: PE rank of every slot (rank among the alive slots of its chunk, by row index) and the alive
 // counters the host polls. One workgroup; the kernel boundary is the all-rows barrier.
 __global__ __launch_bounds__(BEGIN_THREADS) void dec_begin_kernel(DecState* st, int slots) {
@@ -693,6 +806,8 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         h.blp = beam->blp;
         hipLaunchKernelGGL(dec_head_kernel<true>, dim3(slots), dim3(256), 0, s, h);
         hipLaunchKernelGGL(beam_pick_kernel, dim3(beam->B), dim3(256), 0, s, b.st, *beam, b.hidden, b.tokens, T, w.vocab, 2);
+    } else if (fused) {
+        hipLaunchKernelGGL(dec_head4_kernel, dim3(slots), dim3(1024), 0, s, h);
     } else {
         hipLaunchKernelGGL(dec_head_kernel<false>, dim3(slots), dim3(256), 0, s, h);
     }

@@ -96,7 +96,7 @@ struct mnx_engine {
     // greedy ticks of up to dec_fused_max rows run as three launches per layer (dec_fused.hip): dec_tile rows per workgroup in
     // the two attention stages (256 threads per row), dec_tile_ff rows in the feed-forward stage; larger ticks keep the
     // 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_TILE_FF, MNX_DEC_FUSED_MAX)
-    int dec_tile = 4, dec_tile_ff = 4, dec_fused_max = 128;
+    int dec_tile = -1, dec_tile_ff = 4, dec_fused_max = 128;   // dec_tile -1: 2 rows per workgroup up to 64 rows of capacity, 4 beyond
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
     // profiling (bench aid)
     bool profiling = false;
@@ -252,6 +252,7 @@ size_t mnx_workspace_bytes(const mnx_engine* h) { return h ? h->bytes : 0; }
 void mnx_destroy(mnx_engine* h) {
     if (!h) return;
     hipSetDevice(h->device);
+    if (const char* sp = getenv("MNX_FUSED_STAMPS")) { (void)hipDeviceSynchronize(); dec_fused_dump_stamps(sp); }   // lab aid
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     if (h->enc_stream) hipStreamDestroy(h->enc_stream);
@@ -301,9 +302,9 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     if (const char* e = getenv("MNX_DEC_TILE")) h->dec_tile = atoi(e);              // 0: never use the fused tick
     if (const char* e = getenv("MNX_DEC_TILE_FF")) h->dec_tile_ff = atoi(e);
     if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity that runs fused
-    if ((h->dec_tile != 0 && h->dec_tile != 2 && h->dec_tile != 4) ||
+    if ((h->dec_tile != -1 && h->dec_tile != 0 && h->dec_tile != 2 && h->dec_tile != 4) ||
         (h->dec_tile_ff != 4 && h->dec_tile_ff != 8 && h->dec_tile_ff != 16)) {
-        g_create_error = "mnx_create: MNX_DEC_TILE must be 0, 2 or 4 and MNX_DEC_TILE_FF 4, 8 or 16";
+        g_create_error = "mnx_create: MNX_DEC_TILE must be -1 (auto), 0, 2 or 4 and MNX_DEC_TILE_FF 4, 8 or 16";
         delete h;
         return MNX_ERR_INVALID_ARG;
     }
@@ -715,7 +716,8 @@ static int tick_tile(const mnx_engine* h, int rows) {
     const mnx_config& c = h->cfg;
     if (c.dec_ff != 1024 || c.dec_heads != 8 || c.dec_dim != 256 || c.max_len + 1 > 512 || h->db.S > 160) return 0;
     if (h->dec_tile == 0 || rows > h->dec_fused_max || rows % 16) return 0;
-    return 100 * h->dec_tile + h->dec_tile_ff;
+    const int r = h->dec_tile > 0 ? h->dec_tile : (rows <= 64 ? 2 : 4);
+    return 100 * r + h->dec_tile_ff;
 }
 
 static int get_tick_graph(mnx_engine* h, int slots, int rows, float* trace, int trace_rows, hipStream_t s,
