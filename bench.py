@@ -203,6 +203,19 @@ def cpu_baseline(ck, budget_s=85.0):
             "host": host, "thread_sweep": sweep, "runs": rows}
 
 
+def sustained_rate_reference():
+    """The sustained 16-bit MFMA rate measured once with tools/probes/mfma_rate.hip (profiles/r03_mfma_sustained_rate.json says
+    where and when); a reference figure, `roofline.peak` stays the guide's nominal 2.5 PFLOP/s."""
+    path = os.path.join(ROOT, "profiles", "r03_mfma_sustained_rate.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        d["source"] = "profiles/r03_mfma_sustained_rate.json (a committed measurement of round 3, not of this run)"
+        return d
+    except OSError:
+        return None
+
+
 def plan_launch(gpus, env, device_count):
     """What `python bench.py --gpus N` must do, decided before anything touches a GPU:
       ("run", world)    run in this process as one of `world` ranks (world == gpus is enforced),
@@ -232,6 +245,79 @@ def spawn_ranks(gpus, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist syntax) -> [0, 1, 2, 3, 8, 10, 11]."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def rank_cpus(local, cpulists, available):
+    """Host CPUs for the rank that drives device `local` of a node with len(cpulists) ranks. cpulists[i]: the CPUs local to
+    device i's PCIe root (sysfs local_cpulist; None when unknown). The ranks whose devices share a NUMA node split that node's
+    CPUs evenly, in device order — 8 ranks each run a polling host thread, a prefetch thread and pinned-memory copies, and a
+    rank that lands on the other socket pays a cross-socket hop on every poll and every H2D / D2H. Without topology
+    information the CPUs this process may use are cut into len(cpulists) contiguous slices. Pure function (unit-tested)."""
+    world = len(cpulists)
+    avail = sorted(available)
+    mine = cpulists[local]
+    if mine:
+        numa = [c for c in mine if c in available]
+        peers = [i for i in range(world) if cpulists[i] == mine]
+        if numa and len(numa) >= len(peers):
+            per, k = len(numa) // len(peers), peers.index(local)
+            return numa[k * per:(k + 1) * per]
+    per = max(1, len(avail) // world)
+    return avail[local * per:(local + 1) * per] or avail
+
+
+def device_cpulists(world):
+    """sysfs local_cpulist of devices 0..world-1 (None where it cannot be read)."""
+    out = []
+    for i in range(world):
+        try:
+            p = torch.cuda.get_device_properties(i)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+                out.append(parse_cpulist(f.read()) or None)
+        except Exception:   # noqa: BLE001 - topology is a hint, never a reason to fail
+            out.append(None)
+    return out
+
+
+def pin_rank(local, world):
+    """Multi-rank runs: bind this rank (and the threads it starts later) to its device's NUMA-local CPUs; returns the set."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = rank_cpus(local, device_cpulists(world), os.sched_getaffinity(0))
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(8, len(cpus))))
+    return cpus
+
+
+def land_records(out, kmax, rank, world, n_local, pinned, gather=False):
+    """The N > 1 tail of a step group: device result tensors of THIS rank's n_local images -> fixed-size records sized by the
+    largest molecule of the whole job (one scalar all-reduce MAX) -> one all-gather over RCCL / xGMI (gloo in the CPU tests)
+    -> pinned host memory: rank 0 lands the gathered whole (rank order = image order), every other rank its own shard."""
+    tokens, lengths, atom_idx, n_atoms, edges = (out[k] for k in ("tokens", "lengths", "atom_idx", "n_atoms", "edges"))
+    k = shard.common_atom_capacity(n_atoms, kmax)
+    ai, ed = shard.trim_atoms(atom_idx, edges, k)
+    rec = shard.pack_records_device(tokens, lengths, ai, n_atoms, ed)
+    if world > 1 or gather:
+        rec = shard.gather_records(rec, force=gather)
+    mine = rec if (rank == 0 or world == 1) else rec[rank * n_local:(rank + 1) * n_local]
+    dst = pinned[:mine.numel()].view(mine.shape)
+    dst.copy_(mine, non_blocking=True)
+    return dst, k
 
 
 def main():
@@ -266,6 +352,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rank_cpu_set = pin_rank(local, world)         # before the engine starts its helper threads
     use_dist = world > 1 or ("RANK" in os.environ and args.force_gather)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -302,18 +389,9 @@ def main():
         stats["lens"], stats["atoms"] = lengths.cpu().numpy(), n_atoms.cpu().numpy()
         rec = None
         if max_len == shard.MAX_LEN and land:
-            # records sized by the largest molecule of the whole job (one scalar all-reduce), not by max_atoms
-            k = shard.common_atom_capacity(n_atoms, kmax)
-            ai, ed = shard.trim_atoms(atom_idx, edges, k)
-            rec = shard.pack_records_device(tokens, lengths, ai, n_atoms, ed)
-            if world > 1 or args.force_gather:   # result gather over xGMI: fixed-size records, one RCCL all-gather
-                rec = shard.gather_records(rec, force=args.force_gather)
-            # results land in pinned host memory: every rank keeps its own shard, rank 0 the gathered whole
-            mine = rec if (rank == 0 or world == 1) else rec[rank * count * BATCH:(rank + 1) * count * BATCH]
-            dst = host_buf["pinned"][:mine.numel()].view(mine.shape)
-            dst.copy_(mine, non_blocking=True)
+            res = {"tokens": tokens, "lengths": lengths, "atom_idx": atom_idx, "n_atoms": n_atoms, "edges": edges}
+            rec, _ = land_records(res, kmax, rank, world, count * BATCH, host_buf["pinned"], gather=args.force_gather)
             torch.cuda.current_stream().synchronize()
-            rec = dst
         else:
             torch.cuda.current_stream().synchronize()
         return rec
@@ -390,7 +468,8 @@ def main():
         s34 = s_flop / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
         s34_iso = si_flop / (si_ms * 1e-3) / 1e12 if si_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        for name in (f"r03_gemm_traffic_{args.dtype}_b{eb}.json", f"r02_gemm_traffic_b{eb}.json"):
+        for name in (f"r04_gemm_traffic_{args.dtype}_b{eb}.json", f"r03_gemm_traffic_{args.dtype}_b{eb}.json",
+                     f"r02_gemm_traffic_b{eb}.json"):
             if name.startswith("r02") and args.dtype != "bf16":
                 continue
             tpath = os.path.join(ROOT, "profiles", name)
@@ -406,8 +485,6 @@ def main():
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "work": "algorithmic FLOP = 2*M*N*K per launch",
                     "mfma_terms": terms, "frac_of_peak_executed": round(terms * achieved / PEAK_BF16_TFLOPS, 4),
-                    "peak_sustained_measured": {"value": 2220.0, "unit": "TFLOP/s", "how": "register-only MFMA loop on all 256 CUs for "
-                                                "60-120 ms (tools/probes/mfma_rate.hip, DESIGN.md 6.3d); `peak` stays the nominal figure"},
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb, 2 if split else 1)),
                     "images_per_launch": eb,
@@ -503,7 +580,10 @@ def main():
                        "atoms_mean": round(float(np.mean(main_stats["atoms"])), 1),
                        "parallelism": f"dp{world} (shard by image, no data-path collective)"},
             "rccl_ranks": rccl_ranks,
+            "host_cpus_per_rank": len(rank_cpu_set) if rank_cpu_set else None,
             "roofline": roofline, "roofline_extra": extra, "sub_results": sub, "cpu_baseline": cpu,
+            # NOT measured in this run (kept out of `roofline` for that reason): what the matrix pipes sustain on this chip
+            "references": {"mfma_sustained_rate": sustained_rate_reference()},
             "parity_note": ("SMILES exact-match vs the reference is checked on the raw token SMILES + atom / bond sets (RDKit is not "
                             "installable here). dtype fp16x3 (this line's default) and fp32: logits within 1e-3, every token / atom / "
                             "bond equal to the reference from pixels (tests/test_gpu_pixels.py, 32 + 6 images, free-running and "

@@ -244,23 +244,33 @@ __device__ __forceinline__ void wstore256(const WRegs<NROWS, NW>& w, float* ws) 
 // tile — the decode tick's row tiles are 2-4 rows, a 16-row MFMA tile would be 3/4 padding. A chain over k is a
 // sequential exact-fp32 fmaf chain in program order: the same numbers whatever the row tile.
 // x: LDS [R][XSTR] (+ k offset), wrow: this lane's weight row in LDS (+ k offset); rows beyond R repeat rows 0..R-1.
-template <int R, int XSTR>
-__device__ __forceinline__ void chain4(const float* x, const float* wrow, int nk, f32x4 (&acc)[(R + 3) / 4]) {
-    constexpr int NRG = (R + 3) / 4;
+template <int R, int XSTR, int NK>
+__device__ __forceinline__ void chain4(const float* x, const float* wrow, f32x4 (&acc)[(R + 3) / 4]) {
+    constexpr int NRG = (R + 3) / 4, NQ = NK / 4;
     const int lane = threadIdx.x & 63;
     const float* xr = x + ((lane & 3) & (R - 1)) * XSTR;
 #pragma unroll
     for (int g = 0; g < NRG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k = 0; k < nk; k += 4) {
-        const f32x4 b4 = *(const f32x4*)(wrow + k);
-        f32x4 a4[NRG];
+    // the chain is NK dependent instructions: its operands are read two quads ahead, so that no step waits for LDS
+    f32x4 b4[3], a4[3][NRG];
 #pragma unroll
-        for (int g = 0; g < NRG; ++g) a4[g] = *(const f32x4*)(xr + g * 4 * XSTR + k);
+    for (int q = 0; q < 2 && q < NQ; ++q) {
+        b4[q] = *(const f32x4*)(wrow + 4 * q);
+#pragma unroll
+        for (int g = 0; g < NRG; ++g) a4[q][g] = *(const f32x4*)(xr + g * 4 * XSTR + 4 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 2 < NQ) {
+            b4[(q + 2) % 3] = *(const f32x4*)(wrow + 4 * (q + 2));
+#pragma unroll
+            for (int g = 0; g < NRG; ++g) a4[(q + 2) % 3][g] = *(const f32x4*)(xr + g * 4 * XSTR + 4 * (q + 2));
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int g = 0; g < NRG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g][e], b4[e], acc[g], 0, 0, 0);
+            for (int g = 0; g < NRG; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q % 3][g][e], b4[q % 3][e], acc[g], 0, 0, 0);
     }
 }
 
@@ -272,7 +282,7 @@ __device__ __forceinline__ void lin256_mfma(const float* xs, const float* ws, f3
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= 4 * NCB) return;
     const int kq = wave & 3, n = min((wave >> 2) * 64 + lane, NCOL - 1);
-    chain4<R, FXS>(xs + 64 * kq, ws + n * FXS + 64 * kq, 64, acc);
+    chain4<R, FXS, 64>(xs + 64 * kq, ws + n * FXS + 64 * kq, acc);
 }
 template <int NCOL, int R>
 __device__ __forceinline__ void lin256_red(const f32x4 (&acc)[(R + 3) / 4], float* red) {
@@ -322,7 +332,7 @@ __device__ __forceinline__ void slice_mfma_store(const float* in /*[R][STR]*/, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= 4) return;
     f32x4 acc[(R + 3) / 4];
-    chain4<R, STR>(in, wsl + (64 * wave + lane) * STR, KW, acc);
+    chain4<R, STR, KW>(in, wsl + (64 * wave + lane) * STR, acc);
 #pragma unroll
     for (int i = 0; i < R; ++i)
         if (row0 + i < n_act) out[(size_t)(row0 + i) * 256 + 64 * wave + lane] = acc[i >> 2][i & 3];

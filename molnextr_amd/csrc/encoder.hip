@@ -837,14 +837,14 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
 }
 
 // > 64 KB of dynamic LDS needs the per-function opt-in, once per device (bit d of `done`: device d has it)
-template <typename K>
-static hipError_t attn_lds_opt_in(K kernel) {
+template <auto Kern>      // keyed on the kernel value: one flag per instantiation (see gemm256.hip)
+static hipError_t attn_lds_opt_in() {
     static unsigned long long done = 0;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
+    e = hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS);
     if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
     return e;
 }
@@ -863,7 +863,7 @@ hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_tab
             const int n_border = shift > 0 ? B * (nWh + nWw - 1) * heads : 0;
 #define MNX_ATTN_PIPE(TT, MASKED, CLS, NITEMS)                                                                          \
     do {                                                                                                                \
-        hipError_t e_ = attn_lds_opt_in(window_attn_pipe_kernel<TT, MASKED>);                                           \
+        hipError_t e_ = attn_lds_opt_in<window_attn_pipe_kernel<TT, MASKED>>();                                           \
         if (e_ != hipSuccess) return e_;                                                                                \
         hipLaunchKernelGGL((window_attn_pipe_kernel<TT, MASKED>), dim3((NITEMS) < 512 ? (NITEMS) : 512), dim3(576), WA_LDS, s,  \
                            (const TT*)qkv16, qkv_lo, rel_table, (TT*)out16, out_lo, H, W, C, heads, shift, CLS, NITEMS); \

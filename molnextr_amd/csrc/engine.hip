@@ -71,6 +71,7 @@ struct mnx_engine {
     int split_mask = SPL_ALL;                               // op classes evaluated with all three product terms
     int* enc_flag = nullptr;                                // device: set when the final LayerNorm sees a non-finite row
     float* zero_bias = nullptr;                             // [2 * widest C] zeros: the bias of the patch-merging reductions
+    int zero_bias_n = 0;
     int tap_item = -1;
     float* tap_dst = nullptr;
     // decoder
@@ -513,6 +514,7 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
         // of a layer that different kernels compute (launch_gemm16 splits by batch size) go through the same additions
         const size_t nz = (size_t)c.embed_dim << c.n_stages;
         h->zero_bias = (float*)P.dalloc(nz * sizeof(float));
+        h->zero_bias_n = (int)nz;
         if (h->zero_bias && hipMemset(h->zero_bias, 0, nz * sizeof(float)) != hipSuccess) P.problems.push_back("hipMemset failed");
     }
     h->enc_flag = (int*)P.dalloc(sizeof(int));
@@ -945,6 +947,7 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
         ~ExitGuard() { (void)hipStreamSynchronize(h->enc_stream); (void)hipStreamSynchronize(s); }
     } exit_guard{h, s};
     // the encoder stream must not start before the caller's stream reaches this point (images ready)
+    HIPCHK(h, hipMemsetAsync(h->enc_flag, 0, sizeof(int), s));     // the range flag is per call (see mnx_predict)
     HIPCHK(h, hipEventRecord(h->ev_poll[0], s));
     HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_poll[0], 0));
     const int n_chunks = (n_img + ref_batch - 1) / ref_batch;
@@ -1070,6 +1073,9 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     int bound = 0;                                    // upper bound of alive rows (host-side, conservative)
     std::vector<std::pair<int, int>> admits;          // (iteration, rows) of every admission
     HIPCHK(h, dec_enqueue_reset(h->db, s));
+    // the range flag is per call: an earlier mnx_encode on a bad input (whose caller did not poll mnx_encoder_status) must
+    // not make THIS job report MNX_ERR_RANGE
+    HIPCHK(h, hipMemsetAsync(h->enc_flag, 0, sizeof(int), s));
     // the encoder stream must not start before the caller's stream reaches this point (images ready)
     HIPCHK(h, hipEventRecord(h->ev_poll[0], s));
     HIPCHK(h, hipStreamWaitEvent(h->enc_stream, h->ev_poll[0], 0));
@@ -1256,6 +1262,7 @@ int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C
     if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     const int dt = dt_base(h->cfg.compute_dtype);
+    if (!bias && N <= h->zero_bias_n) bias = h->zero_bias;
     if (epi & 0x100) {      // test aid: the persistent fp32-output kernel (gemm_res.hip) whatever the dispatch would choose
         epi &= 0xff;
         if (!gemm_res_supports(dt, epi, M, N, K)) { h->err = "mnx_gemm16: shape / epilogue not supported by gemm_res"; return MNX_ERR_INVALID_ARG; }
@@ -1275,6 +1282,10 @@ int mnx_gemm16_split(mnx_engine* h, int32_t epi, const void* A, int64_t a_lo, co
     if (!dt_split(h->cfg.compute_dtype)) { h->err = "mnx_gemm16_split: the engine's compute_dtype is not a split mode"; return MNX_ERR_INVALID_ARG; }
     if (a_lo < 0 || w_lo < 0 || c_lo < 0) { h->err = "mnx_gemm16_split: negative plane offset"; return MNX_ERR_INVALID_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    if (!bias) {            // the kernels take a bias vector unconditionally: the engine's zero vector stands in
+        if (N > h->zero_bias_n) { h->err = "mnx_gemm16_split: bias == NULL needs N <= 2 * the widest stage"; return MNX_ERR_CAPACITY; }
+        bias = h->zero_bias;
+    }
     SplitArgs sp;
     sp.a_lo = (size_t)a_lo; sp.w_lo = (size_t)w_lo; sp.c_lo = (size_t)c_lo; sp.oscale = oscale; sp.terms = terms;
     if (epi & 0x100) {      // test aid: gemm_res.hip whatever the dispatch would choose

@@ -609,16 +609,18 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 
 }  // namespace
 
-// The 144 KiB dynamic-LDS opt-in is a per-device, per-function attribute: set once per (device, instantiation), so that
-// several handles on different GPUs of one process all get it (include/molnextr_hip.h allows that).
-template <typename K>
-static hipError_t lds_opt_in(K kernel, int lds_bytes = P_LDS) {
+// The 144 KiB dynamic-LDS opt-in is a per-device, per-function attribute: set once per (device, kernel), so that several
+// handles on different GPUs of one process all get it (include/molnextr_hip.h allows that). The once-flag is keyed on the
+// kernel VALUE (a type key would be shared by every instantiation with the same signature — all four epilogues of
+// gemm256x3_kernel — and only the first one launched would ever opt in).
+template <auto Kern>
+static hipError_t lds_opt_in(int lds_bytes = P_LDS) {
     static unsigned long long done = 0;          // bit d: device d has the attribute (<= 64 devices per process)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    e = hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
     return e;
 }
@@ -630,23 +632,11 @@ bool gemm256x3_supports(int dtype, int epi, int M, int N, int K) {
     return M > 0 && M % TM == 0 && N % TN == 0 && K % TK == 0 && K >= 2 * TK;
 }
 
-static const float* zero_bias(int n) {      // per-device zero vector for layers without a bias (<= 4096 columns)
-    static const float* z[64] = {};
-    int dev = 0;
-    if (n > 4096 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!z[dev]) {
-        void* p = nullptr;
-        if (hipMalloc(&p, 4096 * sizeof(float)) != hipSuccess || hipMemset(p, 0, 4096 * sizeof(float)) != hipSuccess) return nullptr;
-        z[dev] = (const float*)p;
-    }
-    return z[dev];
-}
-
 hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                             const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
     if (!sp || sp->terms != 3 || !gemm256x3_supports(dtype, epi, M, N, K)) return hipErrorInvalidValue;
     if (epi == EPI_RESID_F32 && !resid) return hipErrorInvalidValue;
-    if (!bias && !(bias = zero_bias(N))) return hipErrorInvalidValue;
+    if (!bias) return hipErrorInvalidValue;     // callers without a bias pass a zero vector (the engine keeps one)
     const SplitArgs spv = *sp;
     const int tm = M / TM, tn = N / TN;
 #ifndef MNX_X3_GRID             // tools/gemm_lab builds variants with fewer workgroups (what bounds the epilogue: the CU or the chip?)
@@ -655,7 +645,7 @@ hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, vo
     const int grid = tm * tn < MNX_X3_GRID ? tm * tn : MNX_X3_GRID;
 #define MNX_G256X3_CASE(TT, E)                                                                                            \
     case E: {                                                                                                             \
-        const hipError_t attr = lds_opt_in(gemm256x3_kernel<TT, E>, X3_LDS);                                              \
+        const hipError_t attr = lds_opt_in<gemm256x3_kernel<TT, E>>(X3_LDS);                                                 \
         if (attr != hipSuccess) return attr;                                                                              \
         hipLaunchKernelGGL((gemm256x3_kernel<TT, E>), dim3(grid), dim3(512), X3_LDS, s, (const TT*)A, (const TT*)W, C,    \
                            bias, resid, M, N, K, tn, tm * tn, spv);                                                       \
@@ -695,7 +685,7 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
     const int grid = tm * tn < 256 ? tm * tn : 256;
 #define MNX_G256_CASE(TT, E, SP)                                                                                          \
     case E: {                                                                                                             \
-        const hipError_t attr = lds_opt_in(gemm256_kernel<TT, E, SP>);                                                    \
+        const hipError_t attr = lds_opt_in<gemm256_kernel<TT, E, SP>>();                                                    \
         if (attr != hipSuccess) return attr;                                                                              \
         hipLaunchKernelGGL((gemm256_kernel<TT, E, SP>), dim3(grid), dim3(512), P_LDS, s, (const TT*)A, (const TT*)W,      \
                            (TT*)C, bias, M, N, K, tn, tm * tn, spv);                                                      \

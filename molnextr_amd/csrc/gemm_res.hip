@@ -246,14 +246,14 @@ bool gemm_res_preferred(int dtype, int epi, int M, int N, int K) {
     return (M / RM) * (N / RN) >= 1024;
 }
 
-template <typename K>
-static hipError_t lds_opt_in_res(K kernel) {
+template <auto Kern>      // keyed on the kernel value: one flag per instantiation (see gemm256.hip)
+static hipError_t lds_opt_in_res() {
     static unsigned long long done = 0;          // bit d: device d has the attribute
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+    e = hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
     if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
     return e;
 }
@@ -270,7 +270,7 @@ hipError_t launch_gemm_res(int dtype, int epi, const void* A, const void* W, flo
     const int grid = tm * tn < 256 ? tm * tn : 256;
 #define MNX_GRES_CASE(TT, E, SP)                                                                                          \
     case E: {                                                                                                             \
-        const hipError_t attr = lds_opt_in_res(gemm_res_kernel<TT, E, SP>);                                               \
+        const hipError_t attr = lds_opt_in_res<gemm_res_kernel<TT, E, SP>>();                                               \
         if (attr != hipSuccess) return attr;                                                                              \
         hipLaunchKernelGGL((gemm_res_kernel<TT, E, SP>), dim3(grid), dim3(512), R_LDS, s, (const TT*)A, (const TT*)W, C,  \
                            bias, resid, M, N, K, tn, tm * tn, spv);                                                       \

@@ -45,8 +45,23 @@ class MnxWeightDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
 
 
+MNX_ERR_RANGE = -6      # include/molnextr_hip.h: the encoder produced non-finite features (fp16 operand range)
+RANGE_FALLBACK = {"fp16x3": "bf16x3", "fp16": "bf16"}    # the same operand structure with the fp32 exponent range
+
+
 class MnxError(RuntimeError):
-    pass
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+def range_fallback_dtype(err, dtype):
+    """The operand mode to retry in when `err` says that an activation left the fp16 range of `dtype` (None: not that case).
+    The reference handles any checkpoint in fp32; a drop-in must not die on one whose activations exceed 65504: the split
+    bf16 mode keeps three-term products with the fp32 exponent range (logits within 1e-3)."""
+    if isinstance(err, MnxError) and err.code == MNX_ERR_RANGE:
+        return RANGE_FALLBACK.get(dtype)
+    return None
 
 
 def library_path() -> str:
@@ -204,7 +219,7 @@ class Engine:
 
     def _check(self, rc, what):
         if rc != 0:
-            raise MnxError(f"{what} failed ({rc}): {self.lib.mnx_last_error(self.h).decode()}")
+            raise MnxError(f"{what} failed ({rc}): {self.lib.mnx_last_error(self.h).decode()}", code=int(rc))
 
     @property
     def workspace_bytes(self) -> int:

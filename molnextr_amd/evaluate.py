@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import sys
 from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -187,8 +188,21 @@ def main(argv=None):
     engine = Engine(states["encoder"], states["decoder"], device=local, max_batch=64, dtype=dtype)
     df = pd.read_csv(os.path.join(args.data_path, args.test_file))
     paths = [os.path.join(args.data_path, p) for p in df["file_path"]]
-    preds = run_inference(engine, lambda i: load_image_rgb(paths[i]), len(df), args.batch_size, rank, world,
-                          pad_to_square=args.test_file in PAD_TO_SQUARE_FILES)
+    def infer(e):
+        return run_inference(e, lambda i: load_image_rgb(paths[i]), len(df), args.batch_size, rank, world,
+                             pad_to_square=args.test_file in PAD_TO_SQUARE_FILES)
+    try:
+        preds = infer(engine)
+    except Exception as err:     # noqa: BLE001 - only the operand-range case is handled, everything else is re-raised
+        from .engine import range_fallback_dtype
+        to = range_fallback_dtype(err, dtype)
+        if to is None:
+            raise
+        # the reference evaluates any checkpoint; an activation beyond the fp16 range must not end the run
+        print(f"[rank {rank}] {err}: repeating the evaluation with --dtype {to}", file=sys.stderr, flush=True)
+        engine.close()
+        engine = Engine(states["encoder"], states["decoder"], device=local, max_batch=64, dtype=to)
+        preds = infer(engine)
     if rank == 0:
         if "image_id" not in df.columns:    # main.py:461-462
             df["image_id"] = [p.split("/")[-1].split(".")[0] for p in df["file_path"]]

@@ -151,11 +151,33 @@ class molnextr:
         self.device = device
         self.args = args
         self.tokenizer = get_tokenizer(args)
+        self._states, self._max_batch = states, max_batch      # kept for the operand-range fallback (_with_fallback)
         self.engine = Engine(states["encoder"], states["decoder"], device=device.index or 0, max_batch=max_batch,
                              dtype=dtype)
         self.input_size = args.input_size
         self.device_preprocess = device_preprocess
         self.group_images = 1024          # images per engine call of the throughput path (whole reference batches)
+
+    def _with_fallback(self, job):
+        """job(engine) -> result. When the engine reports that an activation left the fp16 range of its operand mode
+        (MNX_ERR_RANGE: possible with fp16x3 / fp16 on checkpoints with very large activations), the engine is rebuilt ONCE
+        in the corresponding bf16 mode (fp32 exponent range) with a warning and the job runs again; the instance keeps the
+        new engine. The reference runs such a checkpoint without complaint, so the drop-in must too."""
+        from .engine import range_fallback_dtype
+        try:
+            return job(self.engine)
+        except MnxError as e:
+            to = range_fallback_dtype(e, self.engine.dtype)
+            if to is None:
+                raise
+            import warnings
+            warnings.warn(f"molnextr_amd: an encoder activation left the fp16 range of operand mode '{self.engine.dtype}' "
+                          f"({e}); rebuilding the engine with dtype='{to}' and repeating the batch", RuntimeWarning)
+            dev = self.engine.device
+            self.engine.close()
+            self.engine = Engine(self._states["encoder"], self._states["decoder"], device=dev, max_batch=self._max_batch,
+                                 dtype=to)
+            return job(self.engine)
 
     @staticmethod
     def _get_args(args_states=None):
@@ -226,17 +248,21 @@ class molnextr:
             group = (self.group_images // batch_size) * batch_size
             groups = [input_images[i:i + group] for i in range(0, len(input_images), group)]
             for x in self._prefetched(groups):
-                preds += predict_pipeline(self.engine, x, self.tokenizer, ref_batch_size=batch_size)
+                preds += self._with_fallback(
+                    lambda eng: predict_pipeline(eng, x, self.tokenizer, ref_batch_size=batch_size))
         else:
             step = max(self.engine.max_batch // batch_size, 1) * batch_size
             for i in range(0, len(input_images), step):
                 x = self._transform(input_images[i:i + step])
-                feats = self.engine.encode(x)
-                preds += decode_batch(self.engine, feats, self.tokenizer, ref_batch_size=batch_size,
-                                      compute_confidence=True)
-                if self.engine.encoder_nonfinite():      # fp16 operand range exceeded (mnx_predict reports it by itself)
-                    raise MnxError("encoder features are not finite: an activation left the fp16 range of the operand mode "
-                                   f"'{self.engine.dtype}'; construct molnextr(..., dtype='bf16x3') for this checkpoint")
+
+                def conf_job(eng):
+                    feats = eng.encode(x)
+                    if eng.encoder_nonfinite():          # fp16 operand range exceeded (mnx_predict reports it by itself)
+                        from .engine import MNX_ERR_RANGE
+                        raise MnxError("encoder features are not finite: an activation left the fp16 range of the operand "
+                                       f"mode '{eng.dtype}'", code=MNX_ERR_RANGE)
+                    return decode_batch(eng, feats, self.tokenizer, ref_batch_size=batch_size, compute_confidence=True)
+                preds += self._with_fallback(conf_job)
         from .chem import convert_graph_to_smiles
         smiles_list, molblock_list, _ = convert_graph_to_smiles(
             [p["chartok_coords"]["coords"] for p in preds], [p["chartok_coords"]["symbols"] for p in preds],

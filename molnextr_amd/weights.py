@@ -24,6 +24,7 @@ bit-identical on every machine — the GPU box regenerates them without the refe
 from __future__ import annotations
 
 import math
+import re
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, Tuple
@@ -317,11 +318,51 @@ def synthetic_encoder_state(seed: int = 0, enc: EncoderDims = SWIN_B) -> "Ordere
     return OrderedDict((k, _synth_tensor(k, shp, seed, enc.window)) for k, shp in encoder_spec(enc).items())
 
 
+def _stress_encoder(e: "OrderedDict[str, torch.Tensor]", seed: int) -> None:
+    """Hostile-but-sane value statistics for the ENCODER (the part of the path that runs on reduced-precision operands):
+    what a trained Swin-B can look like and `synthetic_checkpoint(0)` (all matrices std 1/sqrt(fan_in), LN gains ~1) never
+    exercises. In place, keys and shapes untouched:
+      * every LayerNorm gain log-uniform in [0.1, 8] per channel (the output norm's rescaled to unit rms); norm2 (the MLP's input norm) of every fifth block gets
+        two channels x50 (gains up to 400: operands far from the unit scale the split-operand weight scaling assumes);
+      * every Linear weight scaled by its own log-uniform factor: qkv in [0.1, 0.35] (with gains up to 8 in front of it the
+        attention scores still have a standard deviation of a few units: saturated softmaxes would make ANY two fp32
+        implementations disagree), all others in [0.25, 4] — per-matrix standard deviations from 0.008 to 0.35;
+      * relative-position bias tables with std 3, clipped to +-8;
+      * three channels of the patch-embedding norm bias at +-50: outlier channels in the residual stream of stage 1
+        (LayerNorm statistics dominated by a few channels)."""
+    for k in list(e.keys()):
+        t = e[k]
+        leaf = k.rsplit(".", 1)[-1]
+        if k.endswith("relative_position_bias_table"):
+            e[k] = (hash_normal(k + "/stress", tuple(t.shape), 3.0, seed)).clamp_(-8.0, 8.0)
+        elif (".norm" in k or k.endswith(("norm.weight", "norm.bias"))) and leaf == "weight" and t.dim() == 1:
+            u = hash_uniform(k + "/gain", t.numel())
+            g = np.exp(np.log(0.1) + u * (np.log(8.0) - np.log(0.1))).astype(np.float32)
+            m = re.search(r"layers\.(\d+)\.blocks\.(\d+)\.norm2\.weight$", k)
+            if m and int(m.group(2)) % 5 == 1:
+                idx = (hash_uniform(k + "/outlier", 2) * t.numel()).astype(np.int64)
+                g[idx] *= 50.0
+            if k == "transformer.norm.weight":      # the encoder's output norm: same spread of gains, unit-rms features
+                g /= np.sqrt(np.mean(g * g))        # (the synthetic decoder's molecule-like dynamics assume that scale)
+            e[k] = torch.from_numpy(g)
+        elif k.endswith("patch_embed.norm.bias"):
+            idx = (hash_uniform(k + "/outlier", 3) * t.numel()).astype(np.int64)
+            t[idx[0]] = 50.0
+            t[idx[1]] = -50.0
+            t[idx[2]] = 50.0
+        elif leaf == "weight" and t.dim() == 2:
+            u = float(hash_uniform(k + "/scale", 1)[0])
+            lo, hi = (0.1, 0.35) if k.endswith("attn.qkv.weight") else (0.25, 4.0)
+            t.mul_(float(np.exp(np.log(lo) + u * (np.log(hi) - np.log(lo)))))
+
+
 def synthetic_checkpoint(seed: int = 0, enc: EncoderDims = SWIN_B, dec: DecoderDims = DEC,
-                         molecule_like: bool = True) -> dict:
+                         molecule_like: bool = True, stress: bool = False) -> dict:
     """A checkpoint dict with the reference's layout: {'encoder': sd, 'decoder': sd, 'args': {...}}
-    (reference main.py:389-398). Deterministic in (seed, dims)."""
+    (reference main.py:389-398). Deterministic in (seed, dims). stress: see _stress_encoder."""
     e = synthetic_encoder_state(seed, enc)
+    if stress:
+        _stress_encoder(e, seed)
     d = OrderedDict((k, _synth_tensor(k, shp, seed, enc.window)) for k, shp in decoder_spec(dec).items())
     if molecule_like:
         _shape_decode_dynamics(d, dec)

@@ -789,6 +789,60 @@ def test_reference_format_checkpoint_loads_through_public_api(dev, tmp_path):
         molnextr(None, dev)
 
 
+def test_facade_falls_back_to_the_bf16_split_mode_when_fp16_overflows(dev, tmp_path):
+    """A checkpoint the reference runs without complaint but whose MLP hidden state leaves the fp16 range (fc1 of one block
+    x 3e5, its fc2 x 1 / 3e5: activations ~1e6): the default fp16x3 engine reports MNX_ERR_RANGE; the facade must warn,
+    rebuild in bf16x3 (fp32 exponent range) and return what the fp32 oracle returns — not raise. A later call on a sane
+    input must not inherit the flag (it is per call)."""
+    from molnextr_amd.engine import Engine, MnxError, MNX_ERR_RANGE
+    from molnextr_amd.model import molnextr, predict_pipeline
+    from molnextr_amd.tokenizer import get_tokenizer
+    from oracle.decoder import greedy_decode
+    from oracle.swin import encoder_forward
+    ck = W.synthetic_checkpoint(0)
+    p = "transformer.layers.2.blocks.7.mlp."
+    ck["encoder"][p + "fc1.weight"] *= 3e5
+    ck["encoder"][p + "fc1.bias"] *= 3e5
+    ck["encoder"][p + "fc2.weight"] /= 3e5
+    src = str(tmp_path / "big_activations.pth")
+    torch.save({"encoder": ck["encoder"], "decoder": ck["decoder"], "args": ck["args"]}, src)
+    imgs = W.synthetic_images(3, first_index=40)
+    # the engine alone reports the range error, with its code
+    e = Engine(ck["encoder"], ck["decoder"], device=0, max_batch=4, dec_slots=64)
+    try:
+        with pytest.raises(MnxError) as ei:
+            e.predict(imgs.to(dev), ref_batch=3)
+        assert ei.value.code == MNX_ERR_RANGE
+    finally:
+        e.close()
+    m = molnextr(src, dev, max_batch=4)
+    try:
+        assert m.engine.dtype == "fp16x3"
+        with pytest.warns(RuntimeWarning, match="bf16x3"):
+            preds = m._with_fallback(lambda eng: predict_pipeline(eng, imgs.to(dev), m.tokenizer, ref_batch_size=3))
+        assert m.engine.dtype == "bf16x3"
+        ref = greedy_decode(encoder_forward(imgs, ck["encoder"]), ck["decoder"])
+        tok = get_tokenizer()["chartok_coords"]
+        for pr, ids in zip(preds, ref.tokens):
+            d = tok.sequence_to_smiles(ids)
+            assert pr["chartok_coords"]["smiles"] == d["smiles"] and pr["chartok_coords"]["indices"] == d["indices"]
+        # the rebuilt engine serves the next call without another warning
+        again = m._with_fallback(lambda eng: predict_pipeline(eng, imgs.to(dev), m.tokenizer, ref_batch_size=3))
+        assert [q["chartok_coords"]["smiles"] for q in again] == [q["chartok_coords"]["smiles"] for q in preds]
+    finally:
+        m.engine.close()
+
+
+def test_range_flag_is_per_call(eng, dev):
+    """mnx_encode on an input that overflows sets the device flag; a caller that never polls mnx_encoder_status must not
+    make the NEXT mnx_predict (valid images) fail with MNX_ERR_RANGE."""
+    bad = torch.full((1, 3, 384, 384), float("inf"), device=dev)
+    eng.encode(bad)
+    out = eng.predict(W.synthetic_images(2).to(dev), ref_batch=2)     # would raise MnxError(-6) if the flag were sticky
+    assert int(out["lengths"].min()) >= 1
+    assert not eng.encoder_nonfinite()
+
+
 def test_eval_harness_reproduces_reference_batches(eng, dev, tmp_path):
     """molnextr_amd.evaluate.run_inference on image files: DistributedSampler-style shard (world 1 and a simulated
     rank of world 2), per-rank batches of batch_size*2 as reference batches, records -> prediction dicts; must equal the

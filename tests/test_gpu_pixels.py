@@ -211,6 +211,64 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
         pln.close()
 
 
+# feature tolerances on the stress checkpoint: 4x what tests/study_split_terms.py --ckpt stress predicts on the CPU
+# (profiles/r04_stress_emulation.json: fp16x3 max err 9.5e-6, bf16x3 1.2e-4 on unit-rms features with gains up to 3)
+STRESS_FEAT_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "bf16x3": 5e-4}
+
+
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x3", "fp32"])
+def test_stress_checkpoint_from_pixels_vs_reference(mode, golden_dir):
+    """The exact-mode assertions of test_path_from_pixels_vs_reference on a SECOND, hostile checkpoint
+    (W.synthetic_checkpoint(1, stress=True): LayerNorm gains 0.1..8 with x50 outliers, per-matrix weight scales over a 40x
+    range, relative-position biases up to +-8, outlier channels in the residual stream) and other images — the value ranges
+    the fp16 split's assumptions (activations < 65504, per-matrix power-of-two weight scale, 2^10 softmax scale) have to
+    survive on a trained Swin-B. Fixture: the reference's own Encoder / Decoder on the same pixels (tools/gen_golden.py stress)."""
+    from molnextr_amd.engine import Engine
+    from molnextr_amd.model import predict_pipeline
+    g = dict(np.load(os.path.join(golden_dir, "pixels_stress.npz")))
+    with open(os.path.join(golden_dir, "pixels_stress.json")) as f:
+        gpreds = json.load(f)["preds"]["s16"]
+    ck = W.synthetic_checkpoint(1, stress=True)
+    dev = torch.device("cuda:0")
+    eng = Engine(ck["encoder"], ck["decoder"], device=0, max_batch=16, dtype=mode, dec_slots=64)
+    try:
+        x = W.synthetic_images(16, first_index=700).to(dev)
+        feats = eng.encode(x)
+        assert not eng.encoder_nonfinite(), f"{mode}: an activation of the stress checkpoint left the operand range"
+        f = feats.cpu().numpy()[:, ::9, ::16]
+        ferr = float(np.abs(f - g["feat_strided"]).max())
+        frms = float(np.sqrt(((f - g["feat_strided"]) ** 2).mean()))
+        assert ferr < STRESS_FEAT_TOL[mode], (mode, ferr)
+        ids, lens, lp, margin = (g[f"s16_{k}"] for k in ("ids", "lens", "token_logp", "margin"))
+        tf_err, flips, steps = _teacher_forced(eng, feats, ids, lens, lp, margin, 480)
+        assert tf_err < 1e-3, (mode, tf_err)
+        for (b, t, m) in flips:
+            assert m < FLIP_MARGIN_FACTOR * tf_err, (mode, "flip away from a near-tie", b, t, m, tf_err)
+        out = eng.decode_greedy(feats, max_len=480, trace_logits=True)
+        lg = out["logits"].cpu().numpy()
+        logit_err = max(float(np.abs(lg[s] - g[f"s16_logits_step{s}"]).max()) for s in range(4))
+        assert logit_err < 1e-3, (mode, logit_err)
+        rec = {"feature_max_err": ferr, "feature_rms_err": frms, "feature_rms": float(g["feat_rms"][0]),
+               "logit_max_err_steps0_3": logit_err,
+               "teacher_forced": {"steps": steps, "logp_max_err": tf_err, "flips": len(flips)},
+               "ref_margin_min": float(margin[np.isfinite(margin)].min())}
+        if mode in EXACT_MODES:
+            assert not flips, (mode, flips)
+            toks, ln = out["tokens"].cpu().numpy(), out["lengths"].cpu().numpy()
+            assert np.array_equal(ln, lens)
+            for b in range(16):
+                assert np.array_equal(toks[b, :lens[b]], ids[b, :lens[b]]), (mode, "row", b)
+            preds = predict_pipeline(eng, x, ref_batch_size=16)
+            for b, (p, q) in enumerate(zip(preds, gpreds)):
+                c = p["chartok_coords"]
+                assert (c["smiles"] == q["smiles"] and c["symbols"] == q["symbols"] and c["indices"] == q["indices"]
+                        and c["coords"] == q["coords"] and p["edges"] == q["edges"]), (mode, "molecule", b)
+            rec["molecules_exact_atoms_bonds"] = 16
+        _report("stress_" + mode, rec)
+    finally:
+        eng.close()
+
+
 def test_split_mode_error_budget_by_op_class(gold, images, synth_ckpt):
     """Which op classes need the three-term products? fp16x3 engine, 8 images: the feature error vs the reference with
     every class on three terms, with ONE class at a time reduced to the hi.hi term (= that class computed as the plain

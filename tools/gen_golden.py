@@ -400,6 +400,41 @@ def gen_autocast(Encoder, Decoder, args, tok, ck):
     print("pixels autocast fp16:", {k: v for k, v in js.items() if k not in ("what", "molecule_identical_to_fp32")})
 
 
+def gen_stress(Encoder, Decoder, args, tok):
+    """The path from pixels on a SECOND, hostile checkpoint — W.synthetic_checkpoint(1, stress=True): LayerNorm gains in
+    [0.1, 8] with x50 outlier channels, per-matrix weight scales from 0.1 to 4 times the variance-preserving one,
+    relative-position biases up to +-8, outlier channels in the residual stream (molnextr_amd/weights.py::_stress_encoder) —
+    run by the reference's own Encoder / Decoder classes on 16 synthetic images (a different image range than pixels_e2e).
+    Everything test_gpu_pixels.py asserts for the exact operand modes on pixels_e2e is asserted on this fixture too."""
+    N = 16
+    ck = W.synthetic_checkpoint(1, stress=True)
+    enc = Encoder(reference_args()).eval()
+    enc.load_state_dict(ck["encoder"], strict=True)
+    img = W.synthetic_images(N, first_index=700)
+    with torch.no_grad():
+        feats = torch.cat([enc(img[i:i + 4])[0] for i in range(0, N, 4)])
+    out = {"feat_strided": feats[:, ::9, ::16].numpy().copy(), "feat_rms": np.array([float(feats.pow(2).mean().sqrt())]),
+           "feat_absmax": np.array([float(feats.abs().max())])}
+    dec = Decoder(args, tok).eval()
+    dec.load_state_dict(ck["decoder"], strict=True)
+    o, _, _ = _greedy_with_margins(dec, tok, feats, 480)
+    for k, v in o.items():
+        out[f"s16_{k}"] = v
+    fin = np.isfinite(o["margin"])
+    print(f"stress s16: feature rms {out['feat_rms'][0]:.3f} absmax {out['feat_absmax'][0]:.1f} lens {o['lens'].tolist()} "
+          f"margin min {o['margin'][fin].min():.4f} median {np.median(o['margin'][fin]):.3f}")
+    np.savez_compressed(os.path.join(GOLD, "pixels_stress.npz"), **out)
+    with torch.no_grad():
+        preds = dec.decode(feats)
+    js = [{"smiles": p["chartok_coords"]["smiles"], "symbols": p["chartok_coords"]["symbols"],
+           "coords": p["chartok_coords"]["coords"], "indices": p["chartok_coords"]["indices"], "edges": p["edges"]}
+          for p in preds]
+    with open(os.path.join(GOLD, "pixels_stress.json"), "w") as f:
+        json.dump({"images": "W.synthetic_images(16, first_index=700)", "checkpoint": "W.synthetic_checkpoint(1, stress=True)",
+                   "preds": {"s16": js}}, f)
+    print("pixels_stress: atoms", [len(p["symbols"]) for p in js])
+
+
 def gen_crop_pad():
     """CropWhite(pad=50) and PadToSquare of the reference's own data_aug.py (imported through a minimal
     albumentations / cv2 stand-in: both classes are pure numpy apart from a constant-border pad) on ragged pages:
@@ -435,7 +470,7 @@ def main():
     with open(os.path.join(ROOT, "molnextr_amd", "vocab", "vocab_chars.json")) as f:
         assert json.load(f) == tok["chartok_coords"].stoi, "vocab drifted from the reference"
     ck = W.synthetic_checkpoint(0)
-    want = set(sys.argv[1:]) or {"swin", "decoder", "edges", "tokenizer", "e2e", "beam", "pixels", "crop"}
+    want = set(sys.argv[1:]) or {"swin", "decoder", "edges", "tokenizer", "e2e", "beam", "pixels", "stress", "crop"}
     if "swin" in want:
         gen_swin_tiny(Vision_Transformer)
         gen_swin_full(Encoder, args, ck)
@@ -458,6 +493,8 @@ def main():
         gen_pixels(Encoder, Decoder, args, tok, ck)
     if want & {"pixels", "autocast"}:
         gen_autocast(Encoder, Decoder, args, tok, ck)
+    if "stress" in want:
+        gen_stress(Encoder, Decoder, args, tok)
     if "crop" in want:
         gen_crop_pad()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD))}
