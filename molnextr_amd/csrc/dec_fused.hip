@@ -23,13 +23,22 @@
 // buffers and two partial buffers alternate, so no workgroup overwrites what another one of the same launch still reads).
 // 18 + begin + head = 20 launches per tick instead of 50.
 //
-// Arithmetic is defined per ELEMENT, not per thread mapping: every dot product is a fixed set of fmaf / MFMA chains
-// combined in a fixed order, every softmax denominator is 16 strided chains + a butterfly, every P.V is 8 strided chains +
-// a butterfly, whatever the row tile R (4, 8 or 16 rows per workgroup) — a row's results do not depend on the tile size
-// the host picked for the tick's capacity, nor on which other rows share its tile.
+// Geometry. The two attention stages give every ROW 256 threads (R = 2 or 4 rows per workgroup, 512 / 1024 threads): the
+// attention of a row is the old dec_attn_kernel's (key per lane, 32 value chains), so that every K / V row of the slot is
+// requested at once; the linear parts of the stage use whatever waves they need. The feed-forward stage has 256 threads
+// and RC = 4, 8 or 16 rows. What a stage costs at 64 rows is a chain of ~11 short phases (tools/fused_stamps.py prints
+// them from the kernels' own 100 MHz stamps, lab build `make STAMPS=1`), so every load is requested as early as its
+// address is known, in the order of need (a wave's loads return in order: what is asked for first is waited for first).
 //
-// All matrix work is v_mfma_f32_16x16x4_f32 (exact fp32 chains); with R < 16 the spare rows of the 16-row tile repeat
-// rows 0..R-1 and are dropped.
+// Arithmetic is defined per ELEMENT, not per workgroup shape: every dot product is a fixed set of fmaf / MFMA chains
+// combined in a fixed order (K = 256 linears: four 64-long chains, (c0 + c1) + (c2 + c3); the per-head and per-slice
+// partials: one chain), the softmax and P.V orders are those of dec_attn_kernel — a row's numbers do not depend on the row
+// tiles the host picked for the tick's capacity, nor on which other rows share its tile (tests/test_gpu_parity.py checks
+// bit-equality across tiles). The 8-launches-per-layer tick of decoder.hip adds the same products in another order: same
+// tokens, log-probs within 1e-5.
+//
+// Matrix work is v_mfma_f32_4x4x1_16B_f32 (exact fp32; 4 rows x 64 columns per instruction, one k per instruction): with
+// 2-4 row tiles a 16-row MFMA tile is 3/4 padding (measured: qkv phase 1.5 -> 0.5 us).
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -477,11 +486,10 @@ template <int R> struct FbLds {
     static constexpr int xs = 0, qs = xs + R * FXS, cs = qs + R * 32;
     static constexpr int redm = cs + R * FHS, reds = redm + R * 4, po = reds + R * 4;
     static constexpr int psum = po + R * 128;                     // [R][4][256] subtrees of the prologue
-    static constexpr int wos = psum + R * 1024;                   // [256][FHS]
-    static constexpr int ws = wos + 256 * FHS;                    // [32][FXS]; after the q MFMAs: red | ps
-    static constexpr int red = ws, ps = red + 4 * R * 36;                          // red [4][R][32 + 4]
-    static constexpr int end_a = ws + 32 * FXS, end_b = ps + R * PS_CROSS;
-    static constexpr int total = end_a > end_b ? end_a : end_b;
+    static constexpr int ws = psum + R * 1024;                    // [32][FXS]; after the q MFMAs: red | ps | wos [256][FHS]
+    static constexpr int red = ws, ps = red + 4 * R * 36, wos = ps + R * PS_CROSS;            // red [4][R][32 + 4]
+    static constexpr int end_a = ws + 32 * FXS, end_b = wos + 256 * FHS;
+    static constexpr int total = end_a > end_b ? end_a : end_b;   // 64 KB at R = 4: two workgroups per CU
 };
 template <int R> struct FcLds {
     static constexpr int xs = 0, hs = xs + R * FXS;               // hs [R][FFS]

@@ -234,13 +234,13 @@ def main():
     if args.ckpt == "stress":
         ck = W.synthetic_checkpoint(1, stress=True)
         gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "pixels_stress.npz")))
-        case = "s16"
+        case, first = "s16", 700
     else:
         ck = W.synthetic_checkpoint(0)
         gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "pixels_e2e.npz")))
-        case = "m32"
+        case, first = "m32", 0
     N = min(args.images, gold[f"{case}_ids"].shape[0])
-    img = W.synthetic_images(N)
+    img = W.synthetic_images(N, first_index=first)
     ids, lens, g_lp, margin = (gold[f"{case}_{k}"][:N] for k in ("ids", "lens", "token_logp", "margin"))
     T = int(lens.max())
     ids, g_lp, margin = ids[:, :T], g_lp[:, :T], margin[:, :T]

@@ -212,8 +212,9 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
 
 
 # feature tolerances on the stress checkpoint: 4x what tests/study_split_terms.py --ckpt stress predicts on the CPU
-# (profiles/r04_stress_emulation.json: fp16x3 max err 9.5e-6, bf16x3 1.2e-4 on unit-rms features with gains up to 3)
-STRESS_FEAT_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "bf16x3": 5e-4}
+# (profiles/r04_stress_emulation.json: fp16x3 max err 2.6e-5 / rms 1.2e-6, bf16x3 2.7e-4 / 1.4e-5 on unit-rms features; the
+# largest operands it sees: 499 into fc1, 183 into fc2, 79 in the residual stream — far from the fp16 limit)
+STRESS_FEAT_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "bf16x3": 1.2e-3}
 
 
 @pytest.mark.parametrize("mode", ["fp16x3", "bf16x3", "fp32"])

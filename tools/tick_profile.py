@@ -47,7 +47,8 @@ def main(path, out=None):
         lines.append(f"{cap:8d} {len(v):6d} {statistics.median(w):11.1f} {w[len(w) // 10]:11.1f} "
                      f"{statistics.median(x[1] for x in v):11.1f} {statistics.median(x[3] for x in v):11.1f} {v[0][2]:8d}")
     # per-launch view of a tick: median duration of the i-th kernel of the tick, for the smallest and largest capacity
-    for cap in (min(k for k in by if k), max(k for k in by if k)):
+    caps_shown = sorted({c for c in by if c and c <= 256} | {min(k for k in by if k), max(k for k in by if k)})
+    for cap in caps_shown:
         nl = statistics.mode(len(t["seq"]) for t in ticks if t["cap"] == cap)
         sel = [t for t in ticks if t["cap"] == cap and len(t["seq"]) == nl]
         if not sel:
