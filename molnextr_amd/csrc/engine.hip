@@ -514,7 +514,7 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     }
     {   // the reference's PatchMerging.reduction has no bias; every GEMM kernel adds this vector instead, so that the rows
         // of a layer that different kernels compute (launch_gemm16 splits by batch size) go through the same additions
-        const size_t nz = (size_t)c.embed_dim << c.n_stages;
+        const size_t nz = std::max((size_t)c.embed_dim << c.n_stages, (size_t)4096);   // also the stand-in bias of mnx_gemm16_split
         h->zero_bias = (float*)P.dalloc(nz * sizeof(float));
         h->zero_bias_n = (int)nz;
         if (h->zero_bias && hipMemset(h->zero_bias, 0, nz * sizeof(float)) != hipSuccess) P.problems.push_back("hipMemset failed");
