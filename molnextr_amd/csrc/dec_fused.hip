@@ -49,9 +49,9 @@
 
 namespace mnx {
 
-constexpr int FXS = 260;    // LDS row stride (floats) of 256-wide rows: with strides = 4 (mod 32) the lane-per-row ds_read_b128
-constexpr int FHS = 36;     // of the 4x4x1 MFMA's B operand (lane l reads row n0 + l) hits 64 distinct banks per 16-lane group
-constexpr int FFS = 68;     // (32-wide rows; 64-wide rows)
+constexpr int FXS = 260;    // LDS row stride (floats) of the activation rows the MFMA's A operand is read from (256-wide,
+constexpr int FHS = 36;     // 32-wide, 64-wide): = 4 (mod 32), the four rows a ds_read_b128 touches sit in different banks
+constexpr int FFS = 68;
 constexpr int PS_SELF = 512, PS_CROSS = 160;     // score row length (floats): T <= 511 keys, 144 memory rows
 constexpr float QSCALE = 0.17677669529663687f;   // 1 / sqrt(32): onmt scales the query before QK^T
 constexpr int FF_SLICE = 64;                      // hidden units per dec_fc workgroup
@@ -65,17 +65,20 @@ struct FusedArgs {
     float* part_out;         // [8 | 16][part_stride]
     int part_stride;         // floats between two partial planes (slots * 256)
     const float *gamma, *beta;
+    // Weights are read in the TRANSPOSED layout [k][n] (DecLayerW::*_t): lane l of the 4x4x1 MFMA's B operand is column n0 + l,
+    // so one k of 64 columns is one coalesced 256-byte load straight into the operand register — no LDS staging, no barrier
+    // between "weights arrived" and "weights usable", and the kernels' LDS drops from 80-125 KB to 10-40 KB.
     // dec_fa
-    const float *wqkv, *bqkv, *wo;
+    const float *wqkv, *bqkv, *wo;     // wqkv_t [256][768], wo_t [256][256]
     float *kcache, *vcache;  // this layer's self K / V cache [slots, heads, T, 32]
     const float *emb, *pe;
     // dec_fb
-    const float *wq2, *bq2, *wo2;
+    const float *wq2, *bq2, *wo2;      // wq2_t, wo2_t [256][256]
     const float* memk;       // this layer's memory keys: block b, head h at memk + b * mem_stride + h * S * 32; values S * 256 behind
     long long mem_stride;
     int S;
     // dec_fc
-    const float *w1, *b1, *w2;
+    const float *w1, *b1, *w2;         // w1_t [256][dff], w2_t [dff][256]
     int dff;
     int T, heads;
     // lab aid (MNX_FUSED_STAMPS=<file>): [stage][block][phase] 100 MHz wall-clock stamps of the LAST tick, see tools/fused_stamps.py
@@ -118,13 +121,14 @@ __device__ __forceinline__ float dot32(const f32x4 (&q)[8], const f32x4 (&k)[8])
 }
 
 // ---- stage prologue: x = stream (+ tree(partials) + bias) or embedding; stream out; LayerNorm(eps 1e-6) -> xs[r][FXS] ----
-// One wave per row at a time (row r on wave r mod NW), lane c owns columns 4c..4c+3.
-template <int R, int NW, int NP, bool EMB>
-__device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int n_act, bool writer, float* xs) {
+// One wave per row at a time (row r on wave r mod NW), lane c owns columns 4c..4c+3. after_issue(): called once, after the
+// first rows' loads have been requested.
+template <int R, int NW, int NP, bool EMB, typename F>
+__device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int n_act, bool writer, float* xs, F&& after_issue) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RW = (R + NW - 1) / NW;     // rows per wave
     constexpr int UB = RW < 2 ? RW : 2;       // rows whose loads are in flight together
-    if (wave >= R) return;                    // (wave-uniform; no barrier inside)
+    if (wave >= R) { after_issue(); return; } // (wave-uniform; no barrier inside)
     const f32x4 g = ldg4(a.gamma + lane * 4), be = ldg4(a.beta + lane * 4);
     f32x4 bi = {0.f, 0.f, 0.f, 0.f};
     if (NP > 0) bi = ldg4(a.bias_in + lane * 4);
@@ -145,6 +149,7 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int
                 for (int z = 0; z < NP; ++z) p[u][z] = ldg4(a.part_in + (size_t)z * a.part_stride + (size_t)row * 256 + lane * 4);
             }
         }
+        if (i0 == 0) after_issue();           // the kernel's other requests go BEHIND the stream's: first asked, first waited for
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int r = wave + NW * (i0 + u), row = row0 + r;
@@ -213,65 +218,34 @@ __device__ __forceinline__ void prologue_finish(const FusedArgs& a, int row0, in
     *(f32x4*)(xs + rl * FXS + lane * 4) = x * rsqrtf(var + 1e-6f) * pr.g + pr.be;
 }
 
-// ---- NROWS weight rows x 256 k (blocks of 32 consecutive rows of W, block b starting at rowbase[b]) -> registers -> LDS
-// ws[i][FXS]. Thread (lrow = tid >> 3, part = tid & 7): eight lanes cover one 128-byte segment of a row per load instruction.
-template <int NROWS, int NW>
-struct WRegs {
-    static constexpr int RP = NW * 8;                        // rows per pass of the workgroup
-    static constexpr int NPASS = (NROWS + RP - 1) / RP;
-    f32x4 v[NPASS][8];
-};
-template <int NROWS, int NW>
-__device__ __forceinline__ void wload256(WRegs<NROWS, NW>& w, const float* W, const int* rowbase) {
-    const int lrow = threadIdx.x >> 3, part = threadIdx.x & 7;
-#pragma unroll
-    for (int ps = 0; ps < WRegs<NROWS, NW>::NPASS; ++ps) {
-        const int i = ps * WRegs<NROWS, NW>::RP + lrow;
-        if (i < NROWS) {
-            const float* src = W + (size_t)(rowbase[i >> 5] + (i & 31)) * 256 + part * 4;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w.v[ps][j] = ldg4(src + 32 * j);
-        }
-    }
-}
-template <int NROWS, int NW>
-__device__ __forceinline__ void wstore256(const WRegs<NROWS, NW>& w, float* ws) {
-    const int lrow = threadIdx.x >> 3, part = threadIdx.x & 7;
-#pragma unroll
-    for (int ps = 0; ps < WRegs<NROWS, NW>::NPASS; ++ps) {
-        const int i = ps * WRegs<NROWS, NW>::RP + lrow;
-        if (i < NROWS) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) *(f32x4*)(ws + i * FXS + part * 4 + 32 * j) = w.v[ps][j];
-        }
-    }
-}
-
 // ---- the 4-row matrix instruction: v_mfma_f32_4x4x1_16B_f32 = 16 independent 4x4 outer products. Lane l supplies
 // A = x[row l & 3][k] (every block gets the same four rows) and B = W[n0 + l][k]; accumulator register i of lane l is
 // out[row i][n0 + l]: one instruction multiplies 4 rows by 64 columns for ONE k, at a quarter of the 16x16x4 cost per row
 // tile — the decode tick's row tiles are 2-4 rows, a 16-row MFMA tile would be 3/4 padding. A chain over k is a
 // sequential exact-fp32 fmaf chain in program order: the same numbers whatever the row tile.
-// x: LDS [R][XSTR] (+ k offset), wrow: this lane's weight row in LDS (+ k offset); rows beyond R repeat rows 0..R-1.
+// The B operands of a chain are its lane's column of the transposed weights: NK dwords, requested (bload) long before the
+// chain runs. x: LDS [R][XSTR] (+ k offset); rows beyond R repeat rows 0..R-1.
+template <int NK>
+__device__ __forceinline__ void bload(float (&b)[NK], const float* wt, int ldw) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) b[k] = wt[(size_t)k * ldw];
+}
 template <int R, int XSTR, int NK>
-__device__ __forceinline__ void chain4(const float* x, const float* wrow, f32x4 (&acc)[(R + 3) / 4]) {
+__device__ __forceinline__ void chain4(const float* x, const float (&b)[NK], f32x4 (&acc)[(R + 3) / 4]) {
     constexpr int NRG = (R + 3) / 4, NQ = NK / 4;
     const int lane = threadIdx.x & 63;
     const float* xr = x + ((lane & 3) & (R - 1)) * XSTR;
 #pragma unroll
     for (int g = 0; g < NRG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the chain is NK dependent instructions: its operands are read two quads ahead, so that no step waits for LDS
-    f32x4 b4[3], a4[3][NRG];
+    // the chain is NK dependent instructions: its A operands are read two quads ahead, so that no step waits for LDS
+    f32x4 a4[3][NRG];
 #pragma unroll
-    for (int q = 0; q < 2 && q < NQ; ++q) {
-        b4[q] = *(const f32x4*)(wrow + 4 * q);
+    for (int q = 0; q < 2 && q < NQ; ++q)
 #pragma unroll
         for (int g = 0; g < NRG; ++g) a4[q][g] = *(const f32x4*)(xr + g * 4 * XSTR + 4 * q);
-    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (q + 2 < NQ) {
-            b4[(q + 2) % 3] = *(const f32x4*)(wrow + 4 * (q + 2));
 #pragma unroll
             for (int g = 0; g < NRG; ++g) a4[(q + 2) % 3][g] = *(const f32x4*)(xr + g * 4 * XSTR + 4 * (q + 2));
         }
@@ -279,69 +253,67 @@ __device__ __forceinline__ void chain4(const float* x, const float* wrow, f32x4 
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int g = 0; g < NRG; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q % 3][g][e], b4[q % 3][e], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q % 3][g][e], b[4 * q + e], acc[g], 0, 0, 0);
     }
 }
 
-// ---- out[r][c] = xs[r][:] . ws[c][:] over K = 256 as FOUR chains (chain kq: k = 64 kq .. 64 kq + 63 ascending), combined
-// (c0 + c1) + (c2 + c3) through `red`. Unit (column block cb of 64, chain kq) runs on wave kq + 4 cb.
-template <int NCOL, int R>
-__device__ __forceinline__ void lin256_mfma(const float* xs, const float* ws, f32x4 (&acc)[(R + 3) / 4]) {
-    constexpr int NCB = (NCOL + 63) / 64;
+// ---- out[r][c] = xs[r][:] . W[c][:] over K = 256 as EIGHT chains (chain kc: k = 32 kc .. 32 kc + 31 ascending), combined
+// pairwise by index ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7)) through `red`. A column block cb of 64 columns has 8
+// units; a workgroup of NW waves gives every wave CPW = max(1, 8 NCB / NW) consecutive chains of one column block.
+template <int NCOL, int NW>
+struct LinUnit {
+    static constexpr int NCB = (NCOL + 63) / 64;
+    static constexpr int CPW = 8 * NCB > NW ? 8 * NCB / NW : 1;      // chains per wave
+    static constexpr int WPB = 8 / CPW;                               // waves per column block
+    bool active, valid;
+    int kc0, n;            // first chain, local column (< NCOL when valid)
+};
+template <int NCOL, int NW>
+__device__ __forceinline__ LinUnit<NCOL, NW> lin_unit() {
+    typedef LinUnit<NCOL, NW> U;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave >= 4 * NCB) return;
-    const int kq = wave & 3, n = min((wave >> 2) * 64 + lane, NCOL - 1);
-    chain4<R, FXS, 64>(xs + 64 * kq, ws + n * FXS + 64 * kq, acc);
+    U u;
+    u.active = wave < U::WPB * U::NCB;
+    u.kc0 = (wave % U::WPB) * U::CPW;
+    u.n = (wave / U::WPB) * 64 + lane;
+    u.valid = u.active && u.n < NCOL;
+    return u;
 }
-template <int NCOL, int R>
-__device__ __forceinline__ void lin256_red(const f32x4 (&acc)[(R + 3) / 4], float* red) {
-    constexpr int NCB = (NCOL + 63) / 64, RS = NCOL + 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave >= 4 * NCB) return;
-    const int kq = wave & 3, n = (wave >> 2) * 64 + lane;
-    if (n < NCOL) {
+// the unit's chains: xs [R][FXS], bw = the lane's column of the transposed weights for k in [32 kc0, 32 (kc0 + CPW))
+template <int NCOL, int NW, int R>
+__device__ __forceinline__ void lin256_chains(const LinUnit<NCOL, NW>& u, const float* xs,
+                                              const float (&bw)[32 * LinUnit<NCOL, NW>::CPW], float* red) {
+    constexpr int CPW = LinUnit<NCOL, NW>::CPW, RS = NCOL + 4;
+    if (!u.active) return;
 #pragma unroll
-        for (int i = 0; i < R; ++i) red[(kq * R + i) * RS + n] = acc[i >> 2][i & 3];
+    for (int j = 0; j < CPW; ++j) {
+        float b[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) b[k] = bw[32 * j + k];
+        f32x4 acc[(R + 3) / 4];
+        chain4<R, FXS, 32>(xs + 32 * (u.kc0 + j), b, acc);
+        if (u.valid) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) red[((u.kc0 + j) * R + i) * RS + u.n] = acc[i >> 2][i & 3];
+        }
     }
 }
 template <int NCOL, int R>
 __device__ __forceinline__ float red_get(const float* red, int r, int c) {
     constexpr int RS = NCOL + 4;
-    return (red[(0 * R + r) * RS + c] + red[(1 * R + r) * RS + c]) + (red[(2 * R + r) * RS + c] + red[(3 * R + r) * RS + c]);
+    const float* p = red + r * RS + c;
+    return ((p[0 * R * RS] + p[1 * R * RS]) + (p[2 * R * RS] + p[3 * R * RS])) +
+           ((p[4 * R * RS] + p[5 * R * RS]) + (p[6 * R * RS] + p[7 * R * RS]));
 }
 
-// ---- [256 n x KW k] weight slice (k columns k0..k0+KW of a [256, ldw] matrix) -> registers -> LDS [n][STR] ----
-template <int KW, int NW>
-struct SliceRegs {
-    static constexpr int LPR = KW / 4;                  // lanes per row
-    static constexpr int RPI = NW * 64 / LPR;           // rows per load instruction of the workgroup
-    static constexpr int NPASS = 256 / RPI;
-    f32x4 v[NPASS];
-};
-template <int KW, int NW>
-__device__ __forceinline__ void sload(SliceRegs<KW, NW>& s, const float* W, int ldw, int k0) {
-    typedef SliceRegs<KW, NW> S;
-    const int c4 = threadIdx.x % S::LPR, n0 = threadIdx.x / S::LPR;
-#pragma unroll
-    for (int j = 0; j < S::NPASS; ++j) s.v[j] = ldg4(W + (size_t)(n0 + S::RPI * j) * ldw + k0 + c4 * 4);
-}
-template <int KW, int STR, int NW>
-__device__ __forceinline__ void sstore(const SliceRegs<KW, NW>& s, float* dst) {
-    typedef SliceRegs<KW, NW> S;
-    const int c4 = threadIdx.x % S::LPR, n0 = threadIdx.x / S::LPR;
-#pragma unroll
-    for (int j = 0; j < S::NPASS; ++j) *(f32x4*)(dst + (n0 + S::RPI * j) * STR + c4 * 4) = s.v[j];
-}
-
-// ---- partial[row][n] = sum_{k < KW} in[r][k] * wsl[n][k], ONE chain (k ascending) per element: wave cb < 4 owns columns
-// [64 cb, 64 cb + 64) ----
+// ---- partial[row][n] = sum_{k < KW} in[r][k] * W[n][k0 + k], ONE chain (k ascending) per element: wave cb < 4 owns columns
+// [64 cb, 64 cb + 64); its B operands (b, loaded by the caller from wt + k0 * 256 + 64 cb + lane) ----
 template <int KW, int STR, int R>
-__device__ __forceinline__ void slice_mfma_store(const float* in /*[R][STR]*/, const float* wsl /*[256][STR]*/, float* out,
-                                                 int row0, int n_act) {
+__device__ __forceinline__ void slice_mfma_store(const float* in /*[R][STR]*/, const float (&b)[KW], float* out, int row0, int n_act) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= 4) return;
     f32x4 acc[(R + 3) / 4];
-    chain4<R, STR, KW>(in, wsl + (64 * wave + lane) * STR, acc);
+    chain4<R, STR, KW>(in, b, acc);
 #pragma unroll
     for (int i = 0; i < R; ++i)
         if (row0 + i < n_act) out[(size_t)(row0 + i) * 256 + 64 * wave + lane] = acc[i >> 2][i & 3];
@@ -471,75 +443,69 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
     }
 }
 
-// LDS plan (floats) of the three kernels
+// LDS plan (floats) of the three kernels: activations only (the weights never touch LDS)
 template <int R> struct FaLds {
     static constexpr int xs = 0;
     static constexpr int qs = xs + R * FXS, ks = qs + R * 32, vs = ks + R * 32, cs = vs + R * 32;   // [R][32] x3, [R][FHS]
     static constexpr int redm = cs + R * FHS, reds = redm + R * 4, po = reds + R * 4;              // [R][4] x2, [R][4][32]
     static constexpr int psum = po + R * 128;                     // [R][4][256] subtrees of the prologue
-    static constexpr int ws = psum + R * 1024;                    // [96][FXS]; after the qkv MFMAs: red | wos | ps
-    static constexpr int red = ws, wos = red + 4 * R * 100, ps = wos + 256 * FHS;   // red [4][R][96 + 4]
-    static constexpr int end_a = ws + 96 * FXS, end_b = ps + R * PS_SELF;
-    static constexpr int total = end_a > end_b ? end_a : end_b;
+    static constexpr int red = psum + R * 1024;                   // [8][R][96 + 4]
+    static constexpr int ps = red + 8 * R * 100;                  // [R][PS_SELF]
+    static constexpr int total = ps + R * PS_SELF;                // 44.8 KB at R = 4
 };
 template <int R> struct FbLds {
     static constexpr int xs = 0, qs = xs + R * FXS, cs = qs + R * 32;
     static constexpr int redm = cs + R * FHS, reds = redm + R * 4, po = reds + R * 4;
-    static constexpr int psum = po + R * 128;                     // [R][4][256] subtrees of the prologue
-    static constexpr int ws = psum + R * 1024;                    // [32][FXS]; after the q MFMAs: red | ps | wos [256][FHS]
-    static constexpr int red = ws, ps = red + 4 * R * 36, wos = ps + R * PS_CROSS;            // red [4][R][32 + 4]
-    static constexpr int end_a = ws + 32 * FXS, end_b = wos + 256 * FHS;
-    static constexpr int total = end_a > end_b ? end_a : end_b;   // 64 KB at R = 4: two workgroups per CU
+    static constexpr int psum = po + R * 128;
+    static constexpr int red = psum + R * 1024;                   // [8][R][32 + 4]
+    static constexpr int ps = red + 8 * R * 36;                   // [R][PS_CROSS]
+    static constexpr int total = ps + R * PS_CROSS;               // 30.3 KB at R = 4
 };
 template <int R> struct FcLds {
     static constexpr int xs = 0, hs = xs + R * FXS;               // hs [R][FFS]
-    static constexpr int ws = hs + R * FFS;                       // [64][FXS]; after the w_1 MFMAs: red | w2s [256][FFS]
-    static constexpr int red = ws, w2s = red + 4 * R * 68;                         // red [4][R][64 + 4]
-    static constexpr int end_a = ws + 64 * FXS, end_b = w2s + 256 * FFS;
-    static constexpr int total = end_a > end_b ? end_a : end_b;
+    static constexpr int red = hs + R * FFS;                      // [8][R][64 + 4]
+    static constexpr int total = red + 8 * R * 68;                // 13.7 KB at R = 4
 };
 
 // =============================================================================================
 // dec_fa: LN1 (+ embedding | + previous FFN partials) -> q, k, v of one head -> self-attention -> Wo partial
 //   models/decoder.py:254-262 (input norm, self_attn, drop + residual), onmt MultiHeadedAttention
-// 256 threads per row (R rows, 256 R threads): the linear parts use all 4 R waves, the attention 4 waves per row.
+// 256 threads per row (R rows, 256 R threads): the linear parts use the first 8 (then 4) waves, the attention 4 waves per row.
 // =============================================================================================
 template <int R, bool EMB>
 __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef FaLds<R> Ld;
-    constexpr int VP = 8;
-    const int tid = threadIdx.x;
+    constexpr int VP = R >= 4 ? 4 : 8;                   // value rows requested ahead (1024 threads: 128 registers each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, row0 = blockIdx.y * R;
     FSTAMP(0);
     const int4 rv = a.st->rowv[row0 + (tid >> 8)];       // {slot, t, prev_tok, rank} of the row this thread attends for
     const int n_act = a.st->n_active;
-    // requests in the order of need: stream + partials, the head's qkv rows, this thread's key; the value rows and the
-    // head's slice of Wo once the weights have left their registers
+    // requests in the order of need: stream + partials, the unit's 64 weights, this thread's key, then the value rows
     ProRegs<EMB ? 0 : 16> pr;
     prologue_issue<R, EMB ? 0 : 16, EMB>(a, row0, pr);
-    WRegs<96, 4 * R> wv;
-    const int rb[3] = {32 * h, 256 + 32 * h, 512 + 32 * h};
-    wload256<96, 4 * R>(wv, a.wqkv, rb);
+    typedef LinUnit<96, 4 * R> U;
+    const U u = lin_unit<96, 4 * R>();
+    float bw[32 * U::CPW];
+    if (u.active) {                                      // column of wqkv_t: q | k | v of head h
+        const int c = u.valid ? u.n : 0;
+        bload<32 * U::CPW>(bw, a.wqkv + (size_t)(32 * u.kc0) * 768 + (c >> 5) * 256 + 32 * h + (c & 31), 768);
+    }
     const float* Kb = a.kcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
     const float* Vb = a.vcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
     AttnPre<VP> pre;
     attn_prefetch_k<VP>(pre, Kb, rv.y);
     prologue_finish<R, EMB ? 0 : 16, EMB>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum, pr);
     FSTAMP(1);
-    wstore256<96, 4 * R>(wv, smem + Ld::ws);
-    FSTAMP(2);
     attn_prefetch_v<VP>(pre, Vb, rv.y);
-    SliceRegs<32, 4 * R> wov;
-    sload<32, 4 * R>(wov, a.wo, 256, 32 * h);
-    __syncthreads();
+    FSTAMP(2);
+    __syncthreads();                                     // xs complete
     FSTAMP(3);
-    f32x4 acc[1];
-    lin256_mfma<96, R>(smem + Ld::xs, smem + Ld::ws, acc);
-    __syncthreads();                                     // every wave is done with ws: it becomes red | wos | ps
+    lin256_chains<96, 4 * R, R>(u, smem + Ld::xs, bw, smem + Ld::red);
+    float bo[32];                                        // the head's slice of wo_t, columns 64 wave + lane (waves 0..3)
+    if (R < 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);
     FSTAMP(4);
-    lin256_red<96, R>(acc, smem + Ld::red);
-    sstore<32, FHS, 4 * R>(wov, smem + Ld::wos);
     __syncthreads();
     FSTAMP(5);
     for (int idx = tid; idx < R * 96; idx += 256 * R) {
@@ -562,9 +528,10 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     const AttnLds m = {smem + Ld::qs, smem + Ld::ks, smem + Ld::vs, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm,
                        smem + Ld::reds, smem + Ld::po};
     attn_rows<R, false, VP, PS_SELF>(pre, Kb, Vb, rv.y, m, a);
+    if (R >= 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);   // 128 registers per thread: not earlier
     __syncthreads();
     FSTAMP(10);
-    slice_mfma_store<32, FHS, R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    slice_mfma_store<32, FHS, R>(smem + Ld::cs, bo, a.part_out + (size_t)h * a.part_stride, row0, n_act);
     FSTAMP(11);
 }
 
@@ -577,38 +544,34 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef FbLds<R> Ld;
     constexpr int VP = 5;                                // 144 memory rows = 4.5 x 32: every value row is prefetched
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, row0 = blockIdx.y * R;
     FSTAMP(0);
     const int mb = a.st->row_mem[row0 + (tid >> 8)];
     const int n_act = a.st->n_active;
     const float* Kb = a.memk + (size_t)mb * a.mem_stride + (size_t)h * a.S * 32;
     const float* Vb = Kb + (size_t)a.S * 256;
-    // requests in the order of need: stream + partials, the head's query rows, then the memory rows (nothing of this tick
-    // is needed to ask for them, but whatever is requested first is waited for first)
+    // requests in the order of need: stream + partials, the unit's weights, then the memory rows (nothing of this tick is
+    // needed to ask for them, but whatever is requested first is waited for first)
     ProRegs<8> pr;
     prologue_issue<R, 8, false>(a, row0, pr);
-    WRegs<32, 4 * R> wv;
-    const int rb[1] = {32 * h};
-    wload256<32, 4 * R>(wv, a.wq2, rb);
+    typedef LinUnit<32, 4 * R> U;
+    const U u = lin_unit<32, 4 * R>();
+    float bw[32 * U::CPW];
+    if (u.active) bload<32 * U::CPW>(bw, a.wq2 + (size_t)(32 * u.kc0) * 256 + 32 * h + (u.valid ? u.n : 0), 256);
     AttnPre<VP> pre;
     attn_prefetch_k<VP>(pre, Kb, a.S);
     if (R < 4) attn_prefetch_v<VP>(pre, Vb, a.S);
     prologue_finish<R, 8, false>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum, pr);
     FSTAMP(1);
-    wstore256<32, 4 * R>(wv, smem + Ld::ws);
+    if (R >= 4) attn_prefetch_v<VP>(pre, Vb, a.S);      // 1024 threads = 128 registers each: the value rows wait for the prologue's registers
     FSTAMP(2);
-    if (R >= 4) attn_prefetch_v<VP>(pre, Vb, a.S);      // 1024 threads = 128 registers each: the value rows wait for the weights' registers
     __syncthreads();
     FSTAMP(3);
-    SliceRegs<32, 4 * R> wov;
-    sload<32, 4 * R>(wov, a.wo2, 256, 32 * h);
-    f32x4 acc[1];
-    lin256_mfma<32, R>(smem + Ld::xs, smem + Ld::ws, acc);
-    __syncthreads();
+    lin256_chains<32, 4 * R, R>(u, smem + Ld::xs, bw, smem + Ld::red);
+    float bo[32];
+    if (wave < 4) bload<32>(bo, a.wo2 + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);
     FSTAMP(4);
-    lin256_red<32, R>(acc, smem + Ld::red);
-    sstore<32, FHS, 4 * R>(wov, smem + Ld::wos);
     __syncthreads();
     FSTAMP(5);
     for (int idx = tid; idx < R * 32; idx += 256 * R) {
@@ -622,7 +585,7 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     attn_rows<R, true, VP, PS_CROSS>(pre, Kb, Vb, a.S, m, a);
     __syncthreads();
     FSTAMP(10);
-    slice_mfma_store<32, FHS, R>(smem + Ld::cs, smem + Ld::wos, a.part_out + (size_t)h * a.part_stride, row0, n_act);
+    slice_mfma_store<32, FHS, R>(smem + Ld::cs, bo, a.part_out + (size_t)h * a.part_stride, row0, n_act);
     FSTAMP(11);
 }
 
@@ -634,27 +597,24 @@ template <int R>
 __global__ __launch_bounds__(256) void dec_fc_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef FcLds<R> Ld;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sl = blockIdx.x, row0 = blockIdx.y * R;
     FSTAMP(0);
     const int n_act = a.st->n_active;
-    WRegs<64, 4> wv;
-    const int rb[2] = {FF_SLICE * sl, FF_SLICE * sl + 32};
-    wload256<64, 4>(wv, a.w1, rb);
-    fused_prologue<R, 4, 8, false>(a, row0, n_act, sl == 0, smem + Ld::xs);
+    float b1w[64], b2w[64];
+    // wave w: chains 2 w, 2 w + 1 of the slice's 64 hidden units (column 64 sl + lane of w1_t); then columns 64 w + lane of w2_t
+    fused_prologue<R, 4, 8, false>(a, row0, n_act, sl == 0, smem + Ld::xs,
+                                   [&]() {
+                                       bload<64>(b1w, a.w1 + (size_t)(64 * wave) * a.dff + FF_SLICE * sl + lane, a.dff);
+                                       bload<64>(b2w, a.w2 + (size_t)(FF_SLICE * sl) * 256 + 64 * wave + lane, 256);
+                                   });
     FSTAMP(1);
-    wstore256<64, 4>(wv, smem + Ld::ws);
     FSTAMP(2);
-    SliceRegs<64, 4> w2v;
-    sload<64, 4>(w2v, a.w2, a.dff, FF_SLICE * sl);
     __syncthreads();
     FSTAMP(3);
-    f32x4 acc[(R + 3) / 4];
-    lin256_mfma<64, R>(smem + Ld::xs, smem + Ld::ws, acc);
-    __syncthreads();
+    const LinUnit<64, 4> u = lin_unit<64, 4>();
+    lin256_chains<64, 4, R>(u, smem + Ld::xs, b1w, smem + Ld::red);
     FSTAMP(4);
-    lin256_red<64, R>(acc, smem + Ld::red);
-    sstore<64, FFS, 4>(w2v, smem + Ld::w2s);
     __syncthreads();
     FSTAMP(5);
     for (int idx = tid; idx < R * 64; idx += 256) {
@@ -663,7 +623,7 @@ __global__ __launch_bounds__(256) void dec_fc_kernel(FusedArgs a) {
     }
     __syncthreads();
     FSTAMP(10);
-    slice_mfma_store<64, FFS, R>(smem + Ld::hs, smem + Ld::w2s, a.part_out + (size_t)sl * a.part_stride, row0, n_act);
+    slice_mfma_store<64, FFS, R>(smem + Ld::hs, b2w, a.part_out + (size_t)sl * a.part_stride, row0, n_act);
     FSTAMP(11);
 }
 
@@ -726,7 +686,7 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hip
         a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = l > 0 ? w.L[l - 1].b2 : nullptr;
-        a.gamma = Lw.ln1_g; a.beta = Lw.ln1_b; a.wqkv = Lw.wqkv; a.bqkv = Lw.bqkv; a.wo = Lw.wo;
+        a.gamma = Lw.ln1_g; a.beta = Lw.ln1_b; a.wqkv = Lw.wqkv_t; a.bqkv = Lw.bqkv; a.wo = Lw.wo_t;
         a.kcache = b.self_k + (size_t)l * b.slots * H * T * 32;
         a.vcache = b.self_v + (size_t)l * b.slots * H * T * 32;
         if (l == 0) hipLaunchKernelGGL((dec_fa_kernel<R, true>), dim3(H, rows / R), dim3(256 * R), FaLds<R>::total * 4, s, a);
@@ -735,14 +695,14 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hip
         // ---- context-attention block
         a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
-        a.bias_in = Lw.bo; a.gamma = Lw.ln2_g; a.beta = Lw.ln2_b; a.wq2 = Lw.wq2; a.bq2 = Lw.bq2; a.wo2 = Lw.wo2;
+        a.bias_in = Lw.bo; a.gamma = Lw.ln2_g; a.beta = Lw.ln2_b; a.wq2 = Lw.wq2_t; a.bq2 = Lw.bq2; a.wo2 = Lw.wo2_t;
         a.memk = b.mem_kv + (size_t)l * 2 * b.S * D;
         hipLaunchKernelGGL((dec_fb_kernel<R>), dim3(H, rows / R), dim3(256 * R), FbLds<R>::total * 4, s, a);
         ++stage;
         // ---- feed-forward block
         a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
-        a.bias_in = Lw.bo2; a.gamma = Lw.lnf_g; a.beta = Lw.lnf_b; a.w1 = Lw.w1; a.b1 = Lw.b1; a.w2 = Lw.w2;
+        a.bias_in = Lw.bo2; a.gamma = Lw.lnf_g; a.beta = Lw.lnf_b; a.w1 = Lw.w1_t; a.b1 = Lw.b1; a.w2 = Lw.w2_t;
         hipLaunchKernelGGL((dec_fc_kernel<RC>), dim3(w.dff / FF_SLICE, rows / RC), dim3(256), FcLds<RC>::total * 4, s, a);
         ++stage;
     }

@@ -48,6 +48,9 @@ struct DecLayerW {
     const float *wo2, *bo2;        // context_attn.final_linear
     const float *lnf_g, *lnf_b;    // feed_forward.layer_norm
     const float *w1, *b1, *w2, *b2;
+    // transposed copies [k][n] for the fused tick (dec_fused.hip reads a weight column per lane): [256][768], [256][256] x3,
+    // [256][dff], [dff][256]
+    const float *wqkv_t, *wo_t, *wq2_t, *wo2_t, *w1_t, *w2_t;
 };
 
 struct DecWeights {

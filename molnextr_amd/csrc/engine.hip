@@ -422,6 +422,14 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
         }
         dw.pe = P.up32(pe.data(), pe.size());
     }
+    // [rows][cols] -> device [cols][rows]: the fused tick reads a weight COLUMN per lane (dec_fused.hip)
+    auto upT = [&](const float* src, int64_t rows, int64_t cols) -> const float* {
+        if (!src) return nullptr;
+        std::vector<float> t((size_t)rows * cols);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t k = 0; k < cols; ++k) t[(size_t)k * rows + r] = src[(size_t)r * cols + k];
+        return P.up32(t.data(), t.size());
+    };
     std::vector<float> memkv_w((size_t)c.dec_layers * 2 * D * D), memkv_b((size_t)c.dec_layers * 2 * D);
     bool memkv_ok = true;
     for (int l = 0; l < c.dec_layers; ++l) {
@@ -442,12 +450,16 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
             memcpy(&b[0], bq, D * 4); memcpy(&b[D], bk, D * 4); memcpy(&b[2 * D], bv, D * 4);
             L.wqkv = P.up32(w.data(), w.size());
             L.bqkv = P.up32(b.data(), b.size());
+            L.wqkv_t = upT(w.data(), 3 * D, D);
         }
         L.wo = P.f32(p + "self_attn.final_linear.weight", {D, D});
+        L.wo_t = upT(P.host(p + "self_attn.final_linear.weight", {D, D}), D, D);
         L.bo = P.f32(p + "self_attn.final_linear.bias", {D});
         L.wq2 = P.f32(p + "context_attn.linear_query.weight", {D, D});
+        L.wq2_t = upT(P.host(p + "context_attn.linear_query.weight", {D, D}), D, D);
         L.bq2 = P.f32(p + "context_attn.linear_query.bias", {D});
         L.wo2 = P.f32(p + "context_attn.final_linear.weight", {D, D});
+        L.wo2_t = upT(P.host(p + "context_attn.final_linear.weight", {D, D}), D, D);
         L.bo2 = P.f32(p + "context_attn.final_linear.bias", {D});
         const float *ck = P.host(p + "context_attn.linear_keys.weight", {D, D}), *cbk = P.host(p + "context_attn.linear_keys.bias", {D});
         const float *cv = P.host(p + "context_attn.linear_values.weight", {D, D}), *cbv = P.host(p + "context_attn.linear_values.bias", {D});
@@ -460,8 +472,10 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
             memkv_ok = false;
         }
         L.w1 = P.f32(p + "feed_forward.w_1.weight", {FF, D});
+        L.w1_t = upT(P.host(p + "feed_forward.w_1.weight", {FF, D}), FF, D);
         L.b1 = P.f32(p + "feed_forward.w_1.bias", {FF});
         L.w2 = P.f32(p + "feed_forward.w_2.weight", {D, FF});
+        L.w2_t = upT(P.host(p + "feed_forward.w_2.weight", {D, FF}), D, FF);
         L.b2 = P.f32(p + "feed_forward.w_2.bias", {D});
     }
     if (memkv_ok) {
