@@ -97,7 +97,6 @@ struct mnx_engine {
     // greedy ticks of up to dec_fused_max rows run as three launches per layer (dec_fused.hip): dec_tile rows per workgroup in
     // the two attention stages (256 threads per row), dec_tile_ff rows in the feed-forward stage; larger ticks keep the
     // 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_TILE_FF, MNX_DEC_FUSED_MAX)
-    int x3_stagger = 0;        // SplitArgs::stagger in 100 MHz ticks (MNX_X3_STAGGER_US)
     int dec_tile = -1, dec_tile_ff = 4, dec_fused_max = 128;   // dec_tile -1: 2 rows per workgroup up to 64 rows of capacity, 4 beyond
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
     // profiling (bench aid)
@@ -301,7 +300,6 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->device = device;
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
-    if (const char* e = getenv("MNX_X3_STAGGER_US")) h->x3_stagger = (int)(atof(e) * 100.0);
     if (const char* e = getenv("MNX_DEC_TILE")) h->dec_tile = atoi(e);              // 0: never use the fused tick
     if (const char* e = getenv("MNX_DEC_TILE_FF")) h->dec_tile_ff = atoi(e);
     if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity that runs fused
@@ -685,7 +683,7 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     auto gemm = [&](int epi, const void* A, size_t a_lo, const W16& Wt, void* Cc, size_t c_lo, const float* bias,
                     const float* resid, int M, int N, int K, int cls) -> hipError_t {
         SplitArgs sp;
-        sp.a_lo = a_lo; sp.w_lo = Wt.lo; sp.c_lo = c_lo; sp.oscale = Wt.oscale; sp.stagger = h->x3_stagger;
+        sp.a_lo = a_lo; sp.w_lo = Wt.lo; sp.c_lo = c_lo; sp.oscale = Wt.oscale;
         sp.terms = (h->split_mask & cls) ? 3 : 1;
         // kind 4: the Linear layers of the blocks with C >= 512 (Swin-B stages 3 and 4, the MFMA-bound shapes); kind 0: the rest
         return timed((cls != SPL_MERGE && std::min(N, K) >= 512) ? 4 : 0, 2.0 * (double)M * (double)N * (double)K,

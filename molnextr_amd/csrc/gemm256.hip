@@ -404,11 +404,6 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (sp.stagger > 0) {      // de-phase the persistent workgroups (SplitArgs::stagger); every XCD gets all four cohorts
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long d = (unsigned long long)(((blockIdx.x >> 3) & 3) * sp.stagger);
-        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(16);
-    }
     int m0, n0;
     tile_origin(0, m0, n0);
     load_bias(n0);

@@ -26,10 +26,6 @@ struct SplitArgs {
     size_t a_lo = 0, w_lo = 0, c_lo = 0;
     float oscale = 1.f;
     int terms = 3;
-    // gemm256x3_kernel only: cohort c = (workgroup / 8) % 4 starts c * stagger ticks (100 MHz) late, so that the persistent
-    // workgroups do not reach their tile epilogues — 256 or 512 KB of output traffic per CU — all at the same moment
-    // (0 = start together; knob MNX_X3_STAGGER_US)
-    int stagger = 0;
 };
 
 // ---- gemm.hip -------------------------------------------------------------------------------

@@ -137,3 +137,32 @@ def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fe
         assert len(re.findall(r"s_waitcnt vmcnt", loop)) == 0, name          # nothing between the barrier and the loop's back edge ...
         assert len(re.findall(r"s_barrier", body)) == 1, name                 # ... and one barrier per item
         assert len(re.findall(r"ds_read_b64_tr_b16", body)) == 36, name
+
+
+def test_fused_decode_tick_isa_no_scratch_small_row_mfma_and_register_budget(tmp_path):
+    """dec_fused.hip: the three kernels per decoder layer of the greedy tick. What its design rests on, checked in the ISA:
+    (1) no scratch — the 1024-thread instantiations (4 rows per workgroup) have 128 registers per thread and every one of
+    them holds a request in flight; a spill would put scratch round trips into an 8 us kernel; (2) the matrix work is the
+    4-row instruction v_mfma_f32_4x4x1_16b_f32 (no 16-row tile on 2-4 row tiles); (3) the weights never pass through LDS
+    (no LDS-DMA, and the LDS the kernels ask for is activations only: < 64 KB, so two workgroups fit a CU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "molnextr_amd", "csrc", "dec_fused.hip")
+    out = tmp_path / "dec_fused.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN3mnx13dec_f[abc]_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 9          # fa {R = 2, 4} x {embedding, stream}, fb {2, 4}, fc {4, 8, 16}
+    for name, body in kernels:
+        assert "scratch_" not in body, name
+        assert "v_mfma_f32_4x4x1_16b_f32" in body and "v_mfma_f32_16x16x4_f32" not in body, name
+        assert "global_load_lds" not in body, name
+    meta = dict(re.findall(r"\.name:\s+(_ZN3mnx13dec_f[abc]_kernel\w+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text))
+    for name, vg in meta.items():
+        if "ILi4E" in name and ("dec_fa" in name or "dec_fb" in name):
+            assert int(vg) <= 128, (name, vg)             # 1024 threads per workgroup

@@ -1,0 +1,40 @@
+"""CPU: the operand-mode emulation of tests/study_split_terms.py (the tool behind DESIGN.md's split-term / FP8 table) on a
+tiny Swin: its fp32 scheme IS the oracle, and the schemes order as the arithmetic says they must."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from molnextr_amd import weights as W
+from oracle.config import SwinConfig
+from oracle.swin import encoder_forward
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import study_split_terms as ST  # noqa: E402
+
+TINY_W = W.EncoderDims(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)
+TINY_O = SwinConfig(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)
+
+
+def test_emulated_schemes_on_a_tiny_swin():
+    sd = W.synthetic_encoder_state(0, TINY_W)
+    img = W.hash_normal("split_emulation_img", (2, 3, 96, 96), 1.0)
+    ref = encoder_forward(img, sd, TINY_O)
+    f32 = ST.encoder(img, sd, ST.Scheme("fp32"), TINY_O)
+    assert (f32 - ref).abs().max().item() < 2e-5          # same ops; softmax written as exp / sum
+    err = {}
+    for name in ("fp16x3", "bf16x3", "fp16+fp8x2", "fp16x2", "fp16", "bf16"):
+        err[name] = (ST.encoder(img, sd, ST.Scheme(name), TINY_O) - f32).abs().max().item()
+    assert err["fp16x3"] < 2e-5
+    assert err["fp16x3"] < err["bf16x3"] < err["fp16+fp8x2"] < err["fp16"] < err["bf16"], err
+    assert err["bf16x3"] < err["fp16x2"], err              # dropping a correction term costs more than bf16 planes
+
+
+def test_mx8_block_scaling():
+    x = torch.tensor([[1.0, 0.5, 300.0, -448.0] + [0.0] * 28 + [1e-3] * 32])
+    q = ST.mx8(x)
+    assert q.shape == x.shape
+    # block 0: amax 448 -> shared scale 2^0: 300 -> 288 or 320 (3 mantissa bits), 448 exact; block 1 has its own scale
+    assert abs(q[0, 3].item() + 448.0) < 1e-6 and abs(q[0, 2].item() - 300.0) <= 20.0
+    assert np.isclose(q[0, 40].item(), 1e-3, rtol=2 ** -4)
