@@ -1171,12 +1171,17 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         // (one graph per capacity, captured on first use: multiples of 64 up to 1024 rows, of 128 up to 2048, of 256 beyond)
         const int cap_step = bound <= 1024 ? 64 : bound <= 2048 ? 128 : 256;
         const int rows_cap = std::min(SL, (std::max(bound, 1) + cap_step - 1) / cap_step * cap_step);
+        // the begin kernel scans slot tiles 0 .. highest live tag only (tags are handed out lowest-first): a 20-batch job
+        // keeps it to 768 of the 3072 slots — one pass of its 1024 threads instead of three
+        int hi_tag = 0;
+        for (const Chunk& ck : live) hi_tag = std::max(hi_tag, ck.tag);
+        const int scan = std::min(SL, std::max(((hi_tag + 1) * ROW_TILE + 255) / 256 * 256, rows_cap));
         hipGraphExec_t exec = nullptr;
-        rc = get_tick_graph(h, SL, rows_cap, nullptr, 0, s, &exec);
+        rc = get_tick_graph(h, scan, rows_cap, nullptr, 0, s, &exec);
         if (rc != MNX_OK) return rc;
-        rc = run_ticks(h, exec, SL, rows_cap, nullptr, 0, ticks_per_poll, s);
+        rc = run_ticks(h, exec, scan, rows_cap, nullptr, 0, ticks_per_poll, s);
         if (rc != MNX_OK) return rc;
-        HIPCHK(h, dec_enqueue_status(h->db, SL, s));
+        HIPCHK(h, dec_enqueue_status(h->db, scan, s));
         int* snap = pinned + (seq & 1) * (1 + MAX_CHUNKS);
         HIPCHK(h, hipMemcpyAsync(snap, &h->db.st->n_active, (size_t)(1 + MAX_CHUNKS) * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipEventRecord(h->ev_poll[seq & 1], s));
