@@ -14,15 +14,17 @@ import sys
 import numpy as np
 
 BLOCKS, PHASES = 512, 12
-NAMES = {"A": ["issue W + partial loads -> partials summed, LN (1)", "W -> LDS (2)", "K/V/Wo requests, barrier (3)",
-               "qkv MFMA (4)", "red + Wo->LDS, barrier (5)", "combine q/k/v, cache append, barrier (6)",
-               "scores (K arrives), max, barrier (7)", "exp, sum, barrier (8)", "P.V (V arrives), barrier (9)",
-               "ctx, barrier (10)", "Wo partial MFMA + stores (11)"],
-         "B": ["issue K/V/W + partial loads -> partials summed, LN (1)", "W -> LDS (2)", "barrier (3)", "q MFMA (4)",
-               "red + Wo2->LDS, barrier (5)", "combine q, barrier (6)", "scores (K arrives), max, barrier (7)",
-               "exp, sum, barrier (8)", "P.V (V arrives), barrier (9)", "ctx, barrier (10)", "Wo2 partial MFMA + stores (11)"],
-         "C": ["issue W1 + partial loads -> summed, LN (1)", "W1 -> LDS (2)", "W2 request, barrier (3)", "w_1 MFMA (4)",
-               "red + W2->LDS, barrier (5)", None, None, None, None, "GELU, barrier (10)", "w_2 partial MFMA + stores (11)"]}
+NAMES = {"A": ["stream / partial / weight-column / key requests -> partials summed, LN (1)", "value-row requests (2)",
+               "barrier: xs complete (3)", "qkv chains (weights arrive), Wo request (4)", "barrier: chains stored (5)",
+               "combine q/k/v, cache append, barrier (6)", "scores (K arrives), max, barrier (7)", "exp, sum, barrier (8)",
+               "P.V (V arrives), barrier (9)", "ctx, barrier (10)", "Wo partial chain + stores (11)"],
+         "B": ["stream / partial / weight-column / memory-row requests -> partials summed, LN (1)", "value-row requests (2)",
+               "barrier: xs complete (3)", "q chains (weights arrive), Wo2 request (4)", "barrier: chains stored (5)",
+               "combine q, barrier (6)", "scores (K arrives), max, barrier (7)", "exp, sum, barrier (8)",
+               "P.V (V arrives), barrier (9)", "ctx, barrier (10)", "Wo2 partial chain + stores (11)"],
+         "C": ["stream / partial / W1 / W2 column requests -> summed, LN (1)", None, "barrier: xs complete (3)",
+               "w_1 chains (weights arrive) (4)", "barrier: chains stored (5)", None, None, None, None, "GELU, barrier (10)",
+               "w_2 partial chain + stores (11)"]}
 
 
 def show(path):
@@ -45,7 +47,7 @@ def show(path):
                 if NAMES[kind][ph - 1] is None:
                     continue
                 d = blk[:, ph] - blk[:, prev]
-                print(f"      {NAMES[kind][ph - 1]:62s} median {0.01 * np.median(d):6.2f}  max {0.01 * d.max():6.2f} us")
+                print(f"      {NAMES[kind][ph - 1]:84s} median {0.01 * np.median(d):6.2f}  max {0.01 * d.max():6.2f} us")
                 prev = ph
 
 
