@@ -84,6 +84,7 @@ struct FusedArgs {
     // lab aid (MNX_FUSED_STAMPS=<file>): [stage][block][phase] 100 MHz wall-clock stamps of the LAST tick, see tools/fused_stamps.py
     unsigned long long* stamps;
     int stage;
+    int row_base;            // first row of the tick branch this launch belongs to
 };
 constexpr int STAMP_BLOCKS = 512, STAMP_PHASES = 12;
 #ifdef MNX_FUSED_STAMPS     // lab build only (make STAMPS=1): the stamps cost registers in kernels that have none to spare
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     typedef FaLds<R> Ld;
     constexpr int VP = R >= 4 ? 4 : 8;                   // value rows requested ahead (1024 threads: 128 registers each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, row0 = blockIdx.y * R;
+    const int h = blockIdx.x, row0 = a.row_base + blockIdx.y * R;
     FSTAMP(0);
     const int4 rv = a.st->rowv[row0 + (tid >> 8)];       // {slot, t, prev_tok, rank} of the row this thread attends for
     const int n_act = a.st->n_active;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     typedef FbLds<R> Ld;
     constexpr int VP = 5;                                // 144 memory rows = 4.5 x 32: every value row is prefetched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, row0 = blockIdx.y * R;
+    const int h = blockIdx.x, row0 = a.row_base + blockIdx.y * R;
     FSTAMP(0);
     const int mb = a.st->row_mem[row0 + (tid >> 8)];
     const int n_act = a.st->n_active;
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void dec_fc_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef FcLds<R> Ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sl = blockIdx.x, row0 = blockIdx.y * R;
+    const int sl = blockIdx.x, row0 = a.row_base + blockIdx.y * R;
     FSTAMP(0);
     const int n_act = a.st->n_active;
     float b1w[64], b2w[64];
@@ -671,7 +672,7 @@ hipError_t dec_fused_init() {
 
 // R: rows per workgroup of the two attention stages (256 threads per row); RC: rows per workgroup of the feed-forward stage
 template <int R, int RC>
-static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hipStream_t s) {
+static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, hipStream_t s) {
     const int D = 256, H = w.heads, T = b.T;
     int stage = 0;      // stage k reads stream k & 1 and partial buffer (k - 1) & 1, writes stream / partials (k + 1) & 1 / k & 1
     float* xb[2] = {b.x, b.x2};
@@ -680,6 +681,7 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hip
     a.st = b.st; a.part_stride = b.slots * D; a.T = T; a.heads = H; a.emb = w.emb; a.pe = w.pe; a.S = b.S; a.dff = w.dff;
     a.mem_stride = (long long)b.S * w.layers * 2 * D;
     a.stamps = g_stamps;
+    a.row_base = row_base;
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& Lw = w.L[l];
         // ---- self-attention block
@@ -711,16 +713,16 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int rows, hip
 // The 3 x layers kernels of a greedy tick for `rows` rows of capacity (a multiple of 32). row_tile = 10 * R + log2(RC)...:
 // encoded as R * 100 + RC (R in {2, 4}: rows per attention workgroup; RC in {4, 8, 16}: rows per feed-forward workgroup).
 // Returns the stream buffer and the partial buffer the head has to sum (16 partials of the last w_2 + its bias).
-hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int rows, int row_tile, hipStream_t s,
+hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, int row_tile, hipStream_t s,
                                     const float** x_final, const float** part_final) {
     if (w.dff != 16 * FF_SLICE || w.heads != 8 || b.T + 1 > PS_SELF || b.S > PS_CROSS || (rows % 16) || !b.fpart)
         return hipErrorInvalidValue;
     switch (row_tile) {
-        case 204: fused_layers<2, 4>(w, b, rows, s); break;
-        case 208: fused_layers<2, 8>(w, b, rows, s); break;
-        case 404: fused_layers<4, 4>(w, b, rows, s); break;
-        case 408: fused_layers<4, 8>(w, b, rows, s); break;
-        case 416: fused_layers<4, 16>(w, b, rows, s); break;
+        case 204: fused_layers<2, 4>(w, b, row_base, rows, s); break;
+        case 208: fused_layers<2, 8>(w, b, row_base, rows, s); break;
+        case 404: fused_layers<4, 4>(w, b, row_base, rows, s); break;
+        case 408: fused_layers<4, 8>(w, b, row_base, rows, s); break;
+        case 416: fused_layers<4, 16>(w, b, row_base, rows, s); break;
         default: return hipErrorInvalidValue;
     }
     const int stages = 3 * w.layers;

@@ -121,8 +121,11 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
 // dec_fused.hip
 hipError_t dec_fused_init();
 void dec_fused_dump_stamps(const char* path);   // lab aid (MNX_FUSED_STAMPS)
-hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int rows, int row_tile, hipStream_t s,
+hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, int row_tile, hipStream_t s,
                                     const float** x_final, const float** part_final);
+// layers + head of a tick for rows [row_base, row_base + rows) only (after the begin kernel): one BRANCH of a tick
+hipError_t dec_enqueue_tick_rows(const DecWeights& w, const DecBuffers& b, int row_base, int rows, float* logits_trace,
+                                 int trace_rows, hipStream_t s, const BeamBuffers* beam, const int* forced, int fused_tile);
 hipError_t beam_enqueue_init(const DecBuffers& b, const BeamBuffers& bm, int max_len, hipStream_t s);
 hipError_t beam_enqueue_gather(const DecBuffers& b, const BeamBuffers& bm, int out_len, int* o_tokens, int* o_len,
                                float* o_scores, float* o_hidden, hipStream_t s);

@@ -120,6 +120,7 @@ struct LinArgs {
     int N, K, T, heads;
     int part_stride;      // floats between two K-slices of `part` (slots * 256)
     int n_part;           // number of K slices (K / 256 of the linear that wrote them)
+    int row_base;         // first row of the tick branch this launch belongs to (dec_enqueue_tick_rows)
 };
 
 template <int PRO, int EPI>
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
     __shared__ __attribute__((aligned(16))) float ws[TN * XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * TN;
-    const int row0 = blockIdx.y * ROW_TILE;          // rows are positions in the tick's compact active list
+    const int row0 = a.row_base + blockIdx.y * ROW_TILE;   // rows are positions in the tick's compact active list
     // LayerNorm / embedding / staging thread mapping: 8 threads per row, each owns 8 float4 (channels part*4 + 32*j)
     const int lrow = tid >> 3, part = tid & 7;
     f32x4 xv[8], wv[8];
@@ -296,6 +297,7 @@ struct AttnArgs {
     int kstride, fixed_keys, heads, cross;
     const int* anc;      // ANC: [slots, anc_stride] slot that holds key tau of the hypothesis (beam search)
     int anc_stride;
+    int row_base;        // first row of the tick branch
 };
 
 template <bool ANC>
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float po[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
+    const int row = a.row_base + blockIdx.x / a.heads, hd = blockIdx.x % a.heads;
     // no n_active here: an idle row carries the dummy row view (slot 0 at position 0, memory block 0), computes a
     // throw-away context row and touches no per-slot state — one dependent round trip less before the key loads
     const int4 rv = a.st->rowv[row];
@@ -414,6 +416,7 @@ struct HeadArgs {
                            // advances with forced[s][t] instead of its own argmax; tokens[] still records the argmax,
                            // token_logp[] the masked log-prob of the FORCED id
     int V, VP, T, x0, y0, eos, trace_rows;
+    int row_base;          // first row of the tick branch
 };
 
 template <bool BEAM>
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __shared__ float red[8];
     __shared__ int redi[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x;
+    const int row = a.row_base + blockIdx.x;
     const int4 rv = a.st->rowv[row];
     const int n_act = a.st->n_active;
     f32x4 xrow = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(1024) void dec_head4_kernel(HeadArgs a) {
     __shared__ float red[8];
     __shared__ int redi[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = tid & 255, kq = tid >> 8;
-    const int row = blockIdx.x;
+    const int row = a.row_base + blockIdx.x;
     const int4 rv = a.st->rowv[row];
     const int n_act = a.st->n_active;
     const bool valid = col < a.V;
@@ -735,15 +738,23 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
                             int trace_rows, hipStream_t s, const BeamBuffers* beam, const int* forced, int fused_tile) {
     // slots_scan: state slots the begin kernel scans; rows: capacity of the compact active list this tick is
     // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
+    if (beam) hipLaunchKernelGGL(beam_begin_kernel, dim3(1), dim3(256), 0, s, b.st, beam->B, beam->K);
+    else hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
+    return dec_enqueue_tick_rows(w, b, 0, rows, logits_trace, trace_rows, s, beam, forced, fused_tile);
+}
+
+// The layers + head of a tick for rows [row_base, row_base + rows) of the compact active list (the begin kernel has run).
+// Rows are independent through the whole stack, so a tick may be enqueued as several BRANCHES of rows on different streams
+// (engine.hip captures them as parallel branches of the tick graph): every activation buffer is indexed by row.
+hipError_t dec_enqueue_tick_rows(const DecWeights& w, const DecBuffers& b, int row_base, int rows, float* logits_trace,
+                                 int trace_rows, hipStream_t s, const BeamBuffers* beam, const int* forced, int fused_tile) {
     const int D = 256, H = w.heads, T = b.T;
     const int slots = rows;
     const bool split_w2 = beam == nullptr;
     const bool fused = beam == nullptr && fused_tile > 0;
-    if (beam) hipLaunchKernelGGL(beam_begin_kernel, dim3(1), dim3(256), 0, s, b.st, beam->B, beam->K);
-    else hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
     const float *fx = nullptr, *fp = nullptr;
     if (fused) {    // three launches per layer (dec_fused.hip); the head sums the last w_2's 16 partials
-        hipError_t e = dec_enqueue_fused_layers(w, b, rows, fused_tile, s, &fx, &fp);
+        hipError_t e = dec_enqueue_fused_layers(w, b, row_base, rows, fused_tile, s, &fx, &fp);
         if (e != hipSuccess) return e;
     }
     for (int l = 0; l < (fused ? 0 : w.layers); ++l) {
@@ -751,7 +762,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;
         float* vc = b.self_v + (size_t)l * b.slots * H * T * 32;
         LinArgs a = {};
-        a.st = b.st; a.T = T; a.heads = H;
+        a.st = b.st; a.T = T; a.heads = H; a.row_base = row_base;
         // LN1 (+ embedding at layer 0) -> q, k, v
         // the residual stream alternates between two buffers: layer l > 0 sums (stream of layer l-1) + (its w_2 slices)
         // while it normalises them, and column-block 0 writes the sum to the other buffer for the rest of layer l
@@ -765,7 +776,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
         if (l == 0) lin<2, 0>(s, a, slots); else lin<1, 0>(s, a, slots);
         a.part = nullptr;
         AttnArgs at = {};
-        at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
+        at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0; at.row_base = row_base;
         at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32; at.fixed_keys = 0;
         if (beam) {
             at.anc = beam->anc; at.anc_stride = beam->anc_stride;
@@ -801,7 +812,7 @@ hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_
     if (fused) { h.x = fx; h.part = fp; h.tree_bias = w.L[w.layers - 1].b2; } h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
-    h.eos = 2; h.trace_rows = trace_rows; h.forced = forced;
+    h.eos = 2; h.trace_rows = trace_rows; h.forced = forced; h.row_base = row_base;
     if (beam) {
         h.blp = beam->blp;
         hipLaunchKernelGGL(dec_head_kernel<true>, dim3(slots), dim3(256), 0, s, h);

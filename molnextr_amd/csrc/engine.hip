@@ -43,11 +43,12 @@ struct StageW {
 // op classes of the split modes (mnx_set_split_terms)
 enum { SPL_QKV = 1, SPL_ATTN = 2, SPL_PROJ = 4, SPL_FC1 = 8, SPL_FC2 = 16, SPL_MERGE = 32, SPL_ALL = 63 };
 struct GraphKey {
-    int slots, rows, trace, forced, tile;
+    int slots, rows, trace, forced, tile, branches;
     bool operator<(const GraphKey& o) const {
-        return std::tie(slots, rows, trace, forced, tile) < std::tie(o.slots, o.rows, o.trace, o.forced, o.tile);
+        return std::tie(slots, rows, trace, forced, tile, branches) < std::tie(o.slots, o.rows, o.trace, o.forced, o.tile, o.branches);
     }
 };
+constexpr int MAX_TICK_BRANCHES = 8;
 
 }  // namespace
 
@@ -97,7 +98,13 @@ struct mnx_engine {
     // greedy ticks of up to dec_fused_max rows run as three launches per layer (dec_fused.hip): dec_tile rows per workgroup in
     // the two attention stages (256 threads per row), dec_tile_ff rows in the feed-forward stage; larger ticks keep the
     // 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_TILE_FF, MNX_DEC_FUSED_MAX)
-    int dec_tile = -1, dec_tile_ff = 4, dec_fused_max = 128;   // dec_tile -1: 2 rows per workgroup up to 64 rows of capacity, 4 beyond
+    int dec_tile = -1, dec_tile_ff = 4, dec_fused_max = 128;
+    // a tick of more than dec_branch_rows rows is enqueued as up to dec_branch_max BRANCHES of rows on parallel branches of
+    // the tick graph (rows are independent through the whole stack): chains of dependent launches that each leave most
+    // of the chip idle overlap instead of queueing (MNX_DEC_BRANCH_ROWS, 0 = one chain; MNX_DEC_BRANCH_MAX)
+    int dec_branch_rows = 128, dec_branch_max = 4;
+    hipStream_t tick_streams[MAX_TICK_BRANCHES] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_TICK_BRANCHES] = {};   // dec_tile -1: 2 rows per workgroup up to 64 rows of capacity, 4 beyond
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)
     // profiling (bench aid)
     bool profiling = false;
@@ -258,6 +265,11 @@ void mnx_destroy(mnx_engine* h) {
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     if (h->enc_stream) hipStreamDestroy(h->enc_stream);
     if (h->ev_order) hipEventDestroy(h->ev_order);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (int i = 1; i < MAX_TICK_BRANCHES; ++i) {
+        if (h->tick_streams[i]) hipStreamDestroy(h->tick_streams[i]);
+        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+    }
     for (int i = 0; i < 2; ++i) {
         if (h->ev_enc_done[i]) hipEventDestroy(h->ev_enc_done[i]);
         if (h->ev_feat_free[i]) hipEventDestroy(h->ev_feat_free[i]);
@@ -300,6 +312,8 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->device = device;
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
+    if (const char* e = getenv("MNX_DEC_BRANCH_ROWS")) h->dec_branch_rows = atoi(e);
+    if (const char* e = getenv("MNX_DEC_BRANCH_MAX")) h->dec_branch_max = std::max(1, std::min(MAX_TICK_BRANCHES, atoi(e)));
     if (const char* e = getenv("MNX_DEC_TILE")) h->dec_tile = atoi(e);              // 0: never use the fused tick
     if (const char* e = getenv("MNX_DEC_TILE_FF")) h->dec_tile_ff = atoi(e);
     if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity that runs fused
@@ -573,6 +587,11 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&h->enc_stream, hipStreamNonBlocking, hi) != hipSuccess) P.problems.push_back("stream create failed");
         if (hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) != hipSuccess) P.problems.push_back("event create failed");
+        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) P.problems.push_back("event create failed");
+        for (int i = 1; i < MAX_TICK_BRANCHES; ++i)
+            if (hipStreamCreateWithFlags(&h->tick_streams[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess)
+                P.problems.push_back("tick branch stream / event create failed");
     }
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&h->ev_enc_done[i], hipEventDisableTiming) != hipSuccess ||
@@ -736,18 +755,61 @@ static int tick_tile(const mnx_engine* h, int rows) {
     return 100 * r + h->dec_tile_ff;
 }
 
+// Branches of a tick of `rows` rows of capacity: (first row, rows) pairs, multiples of 32 rows, covering [0, rows).
+static int tick_branches(const mnx_engine* h, int rows, bool single, int (*br)[2]) {
+    int nb = 1;
+    if (!single && h->dec_branch_rows > 0 && rows > h->dec_branch_rows)
+        nb = std::min(h->dec_branch_max, (rows + h->dec_branch_rows - 1) / h->dec_branch_rows);
+    const int tiles = rows / ROW_TILE;
+    nb = std::max(1, std::min(nb, tiles));
+    int base = 0;
+    for (int i = 0; i < nb; ++i) {
+        const int t = tiles / nb + (i < tiles % nb ? 1 : 0);
+        br[i][0] = base; br[i][1] = t * ROW_TILE;
+        base += t * ROW_TILE;
+    }
+    return nb;
+}
+
+// One tick on stream s: the begin kernel, then the layers + head of every branch — branch 0 on s, the others on the
+// engine's branch streams between a fork event and join events (under stream capture this records parallel branches of the
+// graph; without a graph it runs the same way eagerly).
+static hipError_t enqueue_tick(mnx_engine* h, int slots, int rows, float* trace, int trace_rows, hipStream_t s,
+                               const int* forced) {
+    int br[MAX_TICK_BRANCHES][2];
+    const int nb = tick_branches(h, rows, trace != nullptr || forced != nullptr, br);
+    hipError_t e = dec_enqueue_status(h->db, slots, s);       // the begin kernel
+    if (e != hipSuccess) return e;
+    if (nb > 1) {
+        if ((e = hipEventRecord(h->ev_fork, s)) != hipSuccess) return e;
+        for (int i = 1; i < nb; ++i)
+            if ((e = hipStreamWaitEvent(h->tick_streams[i], h->ev_fork, 0)) != hipSuccess) return e;
+    }
+    for (int i = 0; i < nb; ++i) {
+        hipStream_t si = i == 0 ? s : h->tick_streams[i];
+        e = dec_enqueue_tick_rows(h->dw, h->db, br[i][0], br[i][1], trace, trace_rows, si, nullptr, forced, tick_tile(h, br[i][1]));
+        if (e != hipSuccess) return e;
+    }
+    for (int i = 1; i < nb; ++i) {
+        if ((e = hipEventRecord(h->ev_join[i], h->tick_streams[i])) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, h->ev_join[i], 0)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 static int get_tick_graph(mnx_engine* h, int slots, int rows, float* trace, int trace_rows, hipStream_t s,
                           hipGraphExec_t* out, const int* forced = nullptr) {
     *out = nullptr;
     if (!h->use_graph) return MNX_OK;
-    const int tile = tick_tile(h, rows);
-    GraphKey key{slots, rows, trace ? trace_rows : 0, forced ? trace_rows : 0, tile};
+    int br[MAX_TICK_BRANCHES][2];
+    const int nb = tick_branches(h, rows, trace != nullptr || forced != nullptr, br);
+    GraphKey key{slots, rows, trace ? trace_rows : 0, forced ? trace_rows : 0, tick_tile(h, br[0][1]), nb};
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { *out = it->second; return MNX_OK; }
     hipGraph_t g = nullptr;
     hipGraphExec_t exec = nullptr;
     HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced, tile);
+    hipError_t e = enqueue_tick(h, slots, rows, trace, trace_rows, s, forced);
     hipError_t e2 = hipStreamEndCapture(s, &g);
     if (e != hipSuccess || e2 != hipSuccess) {
         h->err = std::string("decode tick capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
@@ -764,7 +826,7 @@ static int run_ticks(mnx_engine* h, hipGraphExec_t exec, int slots, int rows, fl
                      hipStream_t s, const int* forced = nullptr) {
     for (int i = 0; i < n; ++i) {
         if (exec) HIPCHK(h, hipGraphLaunch(exec, s));
-        else HIPCHK(h, dec_enqueue_tick(h->dw, h->db, slots, rows, trace, trace_rows, s, nullptr, forced, tick_tile(h, rows)));
+        else HIPCHK(h, enqueue_tick(h, slots, rows, trace, trace_rows, s, forced));
     }
     return MNX_OK;
 }

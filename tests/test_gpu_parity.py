@@ -310,10 +310,12 @@ def test_beam1_equals_greedy(eng, dev):
         assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
 
 
-def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128):
-    """An engine whose greedy tick runs fused on the given row tiles (tile 0: the 8-launches-per-layer tick of decoder.hip)."""
+def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, branch_rows=128, branch_max=4):
+    """An engine whose greedy tick runs fused on the given row tiles (tile 0: the 8-launches-per-layer tick of decoder.hip),
+    ticks of more than branch_rows rows as up to branch_max parallel branches of rows (0: one chain)."""
     from molnextr_amd.engine import Engine
-    keys = {"MNX_DEC_TILE": str(tile), "MNX_DEC_TILE_FF": str(tile_ff), "MNX_DEC_FUSED_MAX": str(fused_max)}
+    keys = {"MNX_DEC_TILE": str(tile), "MNX_DEC_TILE_FF": str(tile_ff), "MNX_DEC_FUSED_MAX": str(fused_max),
+            "MNX_DEC_BRANCH_ROWS": str(branch_rows), "MNX_DEC_BRANCH_MAX": str(branch_max)}
     old = {k: os.environ.get(k) for k in keys}
     os.environ.update(keys)
     try:
@@ -361,8 +363,10 @@ def test_fused_and_unfused_ticks_mix_in_one_job(eng, dev, synth_ckpt):
     (capacity 192) and drains on the fused one. Tokens / atoms / bonds must equal the all-fused and the all-unfused job."""
     imgs = W.synthetic_images(160, first_index=500).to(dev)
     res = []
-    for tile, fmax in ((4, 64), (4, 4096), (0, 0), (2, 128)):
-        e = _engine_with_tick(synth_ckpt, tile, 4, fmax, slots=256)
+    # (tile, fused_max, branch_rows, branch_max): the last three vary how a tick is cut into parallel branches of rows —
+    # one chain, two branches of 96 rows (fused), five of 32, two of 96 on the 8-launch form — which must not change anything
+    for tile, fmax, brows, bmax in ((4, 64, 128, 4), (4, 4096, 0, 1), (0, 0, 0, 1), (2, 128, 128, 4), (4, 128, 32, 8), (0, 0, 96, 2)):
+        e = _engine_with_tick(synth_ckpt, tile, 4, fmax, slots=256, branch_rows=brows, branch_max=bmax)
         try:
             res.append({k: v.cpu() for k, v in e.predict(imgs, ref_batch=32).items()})
         finally:

@@ -14,17 +14,18 @@ try:
     d = json.loads(open("gpurun_out/b_$n.log").read().strip().splitlines()[-1])
     print("$n", d["value"], "mol/s", d["ms_per_step"], "ms/step")
 except Exception as e:
-    print("$n FAILED", e)
+    print("$n FAILED", e, open("gpurun_out/b_$n.log").read()[-400:])
 PY
 }
-run f128 MNX_DEC_FUSED_MAX=128
-run unfused MNX_DEC_TILE=0
-run f256 MNX_DEC_FUSED_MAX=256
-run f512 MNX_DEC_FUSED_MAX=512
-run f1024 MNX_DEC_FUSED_MAX=1024
-run f128_b MNX_DEC_FUSED_MAX=128
-run f512_ff8 MNX_DEC_FUSED_MAX=512 MNX_DEC_TILE_FF=8
-(cd /tmp && env MNX_DEC_FUSED_MAX=4096 timeout 400 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tick_all -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sub > $GRAFT_REPO_ROOT/gpurun_out/prof_tick_all.log 2>&1)
-DB=$(find gpurun_out/prof_tick_all -name "*.db" | head -1)
-python tools/tick_profile.py $DB gpurun_out/tick_profile_all.txt | head -12
+run br128x4 MNX_DEC_BRANCH_ROWS=128
+run br0 MNX_DEC_BRANCH_ROWS=0
+run br128x4_b MNX_DEC_BRANCH_ROWS=128
+run br0_b MNX_DEC_BRANCH_ROWS=0
+run br128x8 MNX_DEC_BRANCH_ROWS=128 MNX_DEC_BRANCH_MAX=8
+run br128x2 MNX_DEC_BRANCH_ROWS=128 MNX_DEC_BRANCH_MAX=2
+run br64x8 MNX_DEC_BRANCH_ROWS=64 MNX_DEC_BRANCH_MAX=8
+run br256x4_old MNX_DEC_BRANCH_ROWS=256 MNX_DEC_BRANCH_MAX=4
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tick_br -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sub > $GRAFT_REPO_ROOT/gpurun_out/prof_tick_br.log 2>&1)
+DB=$(find gpurun_out/prof_tick_br -name "*.db" | head -1)
+python tools/tick_profile.py $DB gpurun_out/tick_profile_br.txt | head -12
 rm -f $DB
