@@ -99,10 +99,12 @@ struct mnx_engine {
     // the two attention stages (256 threads per row), dec_tile_ff rows in the feed-forward stage; larger ticks keep the
     // 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_TILE_FF, MNX_DEC_FUSED_MAX)
     int dec_tile = -1, dec_tile_ff = 4, dec_fused_max = 128;
-    // a tick of more than dec_branch_rows rows is enqueued as up to dec_branch_max BRANCHES of rows on parallel branches of
-    // the tick graph (rows are independent through the whole stack): chains of dependent launches that each leave most
-    // of the chip idle overlap instead of queueing (MNX_DEC_BRANCH_ROWS, 0 = one chain; MNX_DEC_BRANCH_MAX)
-    int dec_branch_rows = 128, dec_branch_max = 4;
+    // a tick of more than dec_branch_rows rows can be enqueued as up to dec_branch_max BRANCHES of rows on parallel branches
+    // of the tick graph (rows are independent through the whole stack). OFF by default (0): measured, the branches of a
+    // hipGraph do overlap but every launch gets slower and the fork / join costs more than the overlap buys — 192 rows as
+    // 2 x 96: 411 us against 374, 640 rows as 4 x 160: 1552 against 572. Kept as a tested knob
+    // (MNX_DEC_BRANCH_ROWS, MNX_DEC_BRANCH_MAX): the row_base plumbing costs nothing.
+    int dec_branch_rows = 0, dec_branch_max = 4;
     hipStream_t tick_streams[MAX_TICK_BRANCHES] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_TICK_BRANCHES] = {};   // dec_tile -1: 2 rows per workgroup up to 64 rows of capacity, 4 beyond
     hipStream_t own_stream = nullptr;   // used when the caller passes the legacy null stream (not capturable)

@@ -310,7 +310,7 @@ def test_beam1_equals_greedy(eng, dev):
         assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
 
 
-def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, branch_rows=128, branch_max=4):
+def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, branch_rows=0, branch_max=4):
     """An engine whose greedy tick runs fused on the given row tiles (tile 0: the 8-launches-per-layer tick of decoder.hip),
     ticks of more than branch_rows rows as up to branch_max parallel branches of rows (0: one chain)."""
     from molnextr_amd.engine import Engine
