@@ -553,7 +553,7 @@ def main():
                 t = timed(lambda: process(eng, x, ns, "pipeline", land=False))
                 sub["throughput_mode_bf16"] = {"what": f"the same {ns} steps with plain bf16 encoder operands (one MFMA term per product): the fastest "
                                                        "mode, NOT token-exact vs the reference (argmax near-ties flip: tests/test_gpu_pixels.py, "
-                                                       "profiles/r03_pixels_parity.json)",
+                                                       "profiles/r04_pixels_parity.json)",
                                                "molecules_per_s": round(ns * BATCH / t, 1)}
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(ck)   # host baseline: rank 0 at N=1 only
         total = args.steps * BATCH * world
@@ -588,7 +588,8 @@ def main():
                             "installable here). dtype fp16x3 (this line's default) and fp32: logits within 1e-3, every token / atom / "
                             "bond equal to the reference from pixels (tests/test_gpu_pixels.py, 32 + 6 images, free-running and "
                             "teacher-forced); bf16x3: logits within 1e-3, flips only on near-ties; plain bf16 / fp16: argmax near-ties "
-                            "flip (profiles/r03_pixels_parity.json, DESIGN.md §6)"),
+                            "flip (profiles/r04_pixels_parity.json, DESIGN.md §6.1, §6.R3); the exact modes also pass on a second, hostile "
+                            "checkpoint (tests/golden/pixels_stress.*)"),
         }
     eng.close()
     if use_dist:

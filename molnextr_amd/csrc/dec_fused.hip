@@ -31,14 +31,16 @@
 // address is known, in the order of need (a wave's loads return in order: what is asked for first is waited for first).
 //
 // Arithmetic is defined per ELEMENT, not per workgroup shape: every dot product is a fixed set of fmaf / MFMA chains
-// combined in a fixed order (K = 256 linears: four 64-long chains, (c0 + c1) + (c2 + c3); the per-head and per-slice
+// combined in a fixed order (K = 256 linears: eight 32-long chains added pairwise by index; the per-head and per-slice
 // partials: one chain), the softmax and P.V orders are those of dec_attn_kernel — a row's numbers do not depend on the row
 // tiles the host picked for the tick's capacity, nor on which other rows share its tile (tests/test_gpu_parity.py checks
 // bit-equality across tiles). The 8-launches-per-layer tick of decoder.hip adds the same products in another order: same
 // tokens, log-probs within 1e-5.
 //
 // Matrix work is v_mfma_f32_4x4x1_16B_f32 (exact fp32; 4 rows x 64 columns per instruction, one k per instruction): with
-// 2-4 row tiles a 16-row MFMA tile is 3/4 padding (measured: qkv phase 1.5 -> 0.5 us).
+// 2-4 row tiles a 16-row MFMA tile is 3/4 padding (measured: qkv phase 1.5 -> 0.5 us). Its B operand is "lane l = column
+// n0 + l": the weights are kept TRANSPOSED [k][n] (DecLayerW::*_t), so one k of 64 columns is one coalesced 256-byte load
+// straight into the operand register — the weights never touch LDS.
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

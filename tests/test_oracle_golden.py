@@ -212,3 +212,24 @@ def test_oracle_from_pixels_vs_reference_golden(golden_dir, synth_ckpt):
         if d["indices"]:
             e, _ = predict_edges(out.hidden[b], d["indices"], synth_ckpt["decoder"])
             assert np.asarray(e).astype(int).tolist() == preds[b]["edges"], f"row {b}: bonds"
+
+
+def test_oracle_from_pixels_on_the_stress_checkpoint_vs_reference_golden(golden_dir):
+    """The same composition on the hostile checkpoint (W.synthetic_checkpoint(1, stress=True): LayerNorm gains 0.1-8 with x50
+    outliers, per-matrix weight scales over 40x, relative-position biases to +-8) against the reference's own classes on the
+    same pixels (pixels_stress.*): features of 4 images, tokens and log-probs of the first 96 steps of the first four rows of
+    its batch (a prefix of a reference batch keeps every row's positional-encoding rank)."""
+    from molnextr_amd import weights as W
+    from oracle.decoder import greedy_decode
+    from oracle.swin import encoder_forward
+    g = np.load(os.path.join(golden_dir, "pixels_stress.npz"))
+    ck = W.synthetic_checkpoint(1, stress=True)
+    feats = encoder_forward(W.synthetic_images(4, first_index=700), ck["encoder"])
+    assert abs(float(g["feat_rms"][0]) - 1.0) < 0.05, "the stress encoder's output norm is rescaled to unit rms"
+    assert np.abs(feats[:, ::9, ::16].numpy() - g["feat_strided"][:4]).max() < 2e-5
+    T = 96          # the first 96 steps (row 0 finishes at 76, the other three run on): enough to pin the composition on the CPU
+    out = greedy_decode(feats, ck["decoder"], max_len=T)
+    for b in range(4):
+        n = min(int(g["s16_lens"][b]), T)
+        assert out.tokens[b] == g["s16_ids"][b, :n].tolist(), f"row {b}"
+        assert np.abs(np.array(out.token_logp[b]) - g["s16_token_logp"][b, :n]).max() < 1e-4
