@@ -87,7 +87,20 @@ struct FusedArgs {
     unsigned long long* stamps;
     int stage;
     int row_base;            // first row of the tick branch this launch belongs to
+    // xcd != 0: the grid is (row tile slot, unit) instead of (unit, row tile) and slot x maps to the row tile whose 4-row group
+    // g satisfies g % 8 == x % 8. Workgroup b runs on XCD b % 8 (observed, for speed only), so every stage then works on a
+    // row's planes on the SAME XCD that wrote them: the consumer's plane loads hit that XCD's L2 instead of missing to memory.
+    int xcd;
 };
+
+// row tile of grid slot x of nt slots, tiles of R rows: consecutive 4-row groups on consecutive XCDs (nt * R / 4 a multiple of 8)
+template <int R>
+__device__ __forceinline__ int xcd_tile(int x, int nt) {
+    if (R >= 4) return x;
+    constexpr int Q = 4 / R;                 // tiles per 4-row group
+    const int groups = nt / Q;
+    return Q * (x % groups) + x / groups;
+}
 constexpr int STAMP_BLOCKS = 512, STAMP_PHASES = 12;
 #ifdef MNX_FUSED_STAMPS     // lab build only (make STAMPS=1): the stamps cost registers in kernels that have none to spare
 #define FSTAMP(ph)                                                                                                        \
@@ -481,7 +494,8 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     typedef FaLds<R> Ld;
     constexpr int VP = R >= 4 ? 4 : 8;                   // value rows requested ahead (1024 threads: 128 registers each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, row0 = a.row_base + blockIdx.y * R;
+    const int h = a.xcd ? blockIdx.y : blockIdx.x;
+    const int row0 = a.row_base + (a.xcd ? xcd_tile<R>(blockIdx.x, gridDim.x) : (int)blockIdx.y) * R;
     FSTAMP(0);
     const int4 rv = a.st->rowv[row0 + (tid >> 8)];       // {slot, t, prev_tok, rank} of the row this thread attends for
     const int n_act = a.st->n_active;
@@ -548,7 +562,8 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     typedef FbLds<R> Ld;
     constexpr int VP = 5;                                // 144 memory rows = 4.5 x 32: every value row is prefetched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, row0 = a.row_base + blockIdx.y * R;
+    const int h = a.xcd ? blockIdx.y : blockIdx.x;
+    const int row0 = a.row_base + (a.xcd ? xcd_tile<R>(blockIdx.x, gridDim.x) : (int)blockIdx.y) * R;
     FSTAMP(0);
     const int mb = a.st->row_mem[row0 + (tid >> 8)];
     const int n_act = a.st->n_active;
@@ -601,7 +616,8 @@ __global__ __launch_bounds__(256) void dec_fc_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef FcLds<R> Ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sl = blockIdx.x, row0 = a.row_base + blockIdx.y * R;
+    const int sl = a.xcd ? blockIdx.y : blockIdx.x;
+    const int row0 = a.row_base + (a.xcd ? xcd_tile<R>(blockIdx.x, gridDim.x) : (int)blockIdx.y) * R;
     FSTAMP(0);
     const int n_act = a.st->n_active;
     float b1w[64], b2w[64];
@@ -674,7 +690,7 @@ hipError_t dec_fused_init() {
 
 // R: rows per workgroup of the two attention stages (256 threads per row); RC: rows per workgroup of the feed-forward stage
 template <int R, int RC>
-static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, hipStream_t s) {
+static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, int xcd, hipStream_t s) {
     const int D = 256, H = w.heads, T = b.T;
     int stage = 0;      // stage k reads stream k & 1 and partial buffer (k - 1) & 1, writes stream / partials (k + 1) & 1 / k & 1
     float* xb[2] = {b.x, b.x2};
@@ -684,6 +700,7 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
     a.mem_stride = (long long)b.S * w.layers * 2 * D;
     a.stamps = g_stamps;
     a.row_base = row_base;
+    a.xcd = (xcd && rows % 32 == 0) ? 1 : 0;
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& Lw = w.L[l];
         // ---- self-attention block
@@ -693,21 +710,23 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
         a.gamma = Lw.ln1_g; a.beta = Lw.ln1_b; a.wqkv = Lw.wqkv_t; a.bqkv = Lw.bqkv; a.wo = Lw.wo_t;
         a.kcache = b.self_k + (size_t)l * b.slots * H * T * 32;
         a.vcache = b.self_v + (size_t)l * b.slots * H * T * 32;
-        if (l == 0) hipLaunchKernelGGL((dec_fa_kernel<R, true>), dim3(H, rows / R), dim3(256 * R), FaLds<R>::total * 4, s, a);
-        else hipLaunchKernelGGL((dec_fa_kernel<R, false>), dim3(H, rows / R), dim3(256 * R), FaLds<R>::total * 4, s, a);
+        const dim3 gab = a.xcd ? dim3(rows / R, H) : dim3(H, rows / R);
+        if (l == 0) hipLaunchKernelGGL((dec_fa_kernel<R, true>), gab, dim3(256 * R), FaLds<R>::total * 4, s, a);
+        else hipLaunchKernelGGL((dec_fa_kernel<R, false>), gab, dim3(256 * R), FaLds<R>::total * 4, s, a);
         ++stage;
         // ---- context-attention block
         a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = Lw.bo; a.gamma = Lw.ln2_g; a.beta = Lw.ln2_b; a.wq2 = Lw.wq2_t; a.bq2 = Lw.bq2; a.wo2 = Lw.wo2_t;
         a.memk = b.mem_kv + (size_t)l * 2 * b.S * D;
-        hipLaunchKernelGGL((dec_fb_kernel<R>), dim3(H, rows / R), dim3(256 * R), FbLds<R>::total * 4, s, a);
+        hipLaunchKernelGGL((dec_fb_kernel<R>), gab, dim3(256 * R), FbLds<R>::total * 4, s, a);
         ++stage;
         // ---- feed-forward block
         a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = Lw.bo2; a.gamma = Lw.lnf_g; a.beta = Lw.lnf_b; a.w1 = Lw.w1_t; a.b1 = Lw.b1; a.w2 = Lw.w2_t;
-        hipLaunchKernelGGL((dec_fc_kernel<RC>), dim3(w.dff / FF_SLICE, rows / RC), dim3(256), FcLds<RC>::total * 4, s, a);
+        hipLaunchKernelGGL((dec_fc_kernel<RC>), a.xcd ? dim3(rows / RC, w.dff / FF_SLICE) : dim3(w.dff / FF_SLICE, rows / RC), dim3(256),
+                           FcLds<RC>::total * 4, s, a);
         ++stage;
     }
 }
@@ -717,14 +736,16 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
 // Returns the stream buffer and the partial buffer the head has to sum (16 partials of the last w_2 + its bias).
 hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, int row_tile, hipStream_t s,
                                     const float** x_final, const float** part_final) {
+    const int xcd = row_tile / 1000;         // 1000 + 100 R + RC: XCD-local row tiles (FusedArgs::xcd)
+    row_tile %= 1000;
     if (w.dff != 16 * FF_SLICE || w.heads != 8 || b.T + 1 > PS_SELF || b.S > PS_CROSS || (rows % 16) || !b.fpart)
         return hipErrorInvalidValue;
     switch (row_tile) {
-        case 204: fused_layers<2, 4>(w, b, row_base, rows, s); break;
-        case 208: fused_layers<2, 8>(w, b, row_base, rows, s); break;
-        case 404: fused_layers<4, 4>(w, b, row_base, rows, s); break;
-        case 408: fused_layers<4, 8>(w, b, row_base, rows, s); break;
-        case 416: fused_layers<4, 16>(w, b, row_base, rows, s); break;
+        case 204: fused_layers<2, 4>(w, b, row_base, rows, xcd, s); break;
+        case 208: fused_layers<2, 8>(w, b, row_base, rows, xcd, s); break;
+        case 404: fused_layers<4, 4>(w, b, row_base, rows, xcd, s); break;
+        case 408: fused_layers<4, 8>(w, b, row_base, rows, xcd, s); break;
+        case 416: fused_layers<4, 16>(w, b, row_base, rows, xcd, s); break;
         default: return hipErrorInvalidValue;
     }
     const int stages = 3 * w.layers;

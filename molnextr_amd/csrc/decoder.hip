@@ -417,6 +417,7 @@ struct HeadArgs {
                            // token_logp[] the masked log-prob of the FORCED id
     int V, VP, T, x0, y0, eos, trace_rows;
     int row_base;          // first row of the tick branch
+    int xcd;               // dec_head4_kernel: workgroup x takes the row whose 4-row group g has g % 8 == x % 8 (FusedArgs::xcd)
 };
 
 template <bool BEAM>
@@ -530,7 +531,8 @@ __global__ __launch_bounds__(1024) void dec_head4_kernel(HeadArgs a) {
     __shared__ float red[8];
     __shared__ int redi[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = tid & 255, kq = tid >> 8;
-    const int row = a.row_base + blockIdx.x;
+    const int groups = gridDim.x >> 2;
+    const int row = a.row_base + (a.xcd ? 4 * ((int)blockIdx.x % groups) + (int)blockIdx.x / groups : (int)blockIdx.x);
     const int4 rv = a.st->rowv[row];
     const int n_act = a.st->n_active;
     const bool valid = col < a.V;
@@ -809,7 +811,7 @@ hipError_t dec_enqueue_tick_rows(const DecWeights& w, const DecBuffers& b, int r
     HeadArgs h = {};
     h.x = (split_w2 && ((w.layers - 1) & 1)) ? b.x2 : b.x; h.part = split_w2 ? b.part : nullptr; h.part_stride = b.slots * D;
     h.n_part = w.dff / 256;
-    if (fused) { h.x = fx; h.part = fp; h.tree_bias = w.L[w.layers - 1].b2; } h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
+    if (fused) { h.x = fx; h.part = fp; h.tree_bias = w.L[w.layers - 1].b2; h.xcd = (fused_tile >= 1000 && rows % 32 == 0) ? 1 : 0; } h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
     h.eos = 2; h.trace_rows = trace_rows; h.forced = forced; h.row_base = row_base;

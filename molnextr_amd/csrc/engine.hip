@@ -99,6 +99,7 @@ struct mnx_engine {
     // the two attention stages (256 threads per row), dec_tile_ff rows in the feed-forward stage; larger ticks keep the
     // 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_TILE_FF, MNX_DEC_FUSED_MAX)
     int dec_tile = -1, dec_tile_ff = 4, dec_fused_max = 128;
+    int dec_xcd = 0;           // fused tick: row tiles pinned to XCDs so that a row's partial planes stay in one L2 (MNX_DEC_XCD)
     // a tick of more than dec_branch_rows rows can be enqueued as up to dec_branch_max BRANCHES of rows on parallel branches
     // of the tick graph (rows are independent through the whole stack). OFF by default (0): measured, the branches of a
     // hipGraph do overlap but every launch gets slower and the fork / join costs more than the overlap buys — 192 rows as
@@ -316,6 +317,7 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->use_graph = !(ng && ng[0] == '1');
     if (const char* e = getenv("MNX_DEC_BRANCH_ROWS")) h->dec_branch_rows = atoi(e);
     if (const char* e = getenv("MNX_DEC_BRANCH_MAX")) h->dec_branch_max = std::max(1, std::min(MAX_TICK_BRANCHES, atoi(e)));
+    if (const char* e = getenv("MNX_DEC_XCD")) h->dec_xcd = atoi(e) != 0;
     if (const char* e = getenv("MNX_DEC_TILE")) h->dec_tile = atoi(e);              // 0: never use the fused tick
     if (const char* e = getenv("MNX_DEC_TILE_FF")) h->dec_tile_ff = atoi(e);
     if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity that runs fused
@@ -754,7 +756,7 @@ static int tick_tile(const mnx_engine* h, int rows) {
     if (c.dec_ff != 1024 || c.dec_heads != 8 || c.dec_dim != 256 || c.max_len + 1 > 512 || h->db.S > 160) return 0;
     if (h->dec_tile == 0 || rows > h->dec_fused_max || rows % 16) return 0;
     const int r = h->dec_tile > 0 ? h->dec_tile : (rows <= 64 ? 2 : 4);
-    return 100 * r + h->dec_tile_ff;
+    return (h->dec_xcd ? 1000 : 0) + 100 * r + h->dec_tile_ff;
 }
 
 // Branches of a tick of `rows` rows of capacity: (first row, rows) pairs, multiples of 32 rows, covering [0, rows).

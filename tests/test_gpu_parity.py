@@ -310,12 +310,12 @@ def test_beam1_equals_greedy(eng, dev):
         assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
 
 
-def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, branch_rows=0, branch_max=4):
+def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, branch_rows=0, branch_max=4, xcd=0):
     """An engine whose greedy tick runs fused on the given row tiles (tile 0: the 8-launches-per-layer tick of decoder.hip),
     ticks of more than branch_rows rows as up to branch_max parallel branches of rows (0: one chain)."""
     from molnextr_amd.engine import Engine
     keys = {"MNX_DEC_TILE": str(tile), "MNX_DEC_TILE_FF": str(tile_ff), "MNX_DEC_FUSED_MAX": str(fused_max),
-            "MNX_DEC_BRANCH_ROWS": str(branch_rows), "MNX_DEC_BRANCH_MAX": str(branch_max)}
+            "MNX_DEC_BRANCH_ROWS": str(branch_rows), "MNX_DEC_BRANCH_MAX": str(branch_max), "MNX_DEC_XCD": str(xcd)}
     old = {k: os.environ.get(k) for k in keys}
     os.environ.update(keys)
     try:
@@ -335,15 +335,15 @@ def test_fused_tick_is_independent_of_the_row_tiles_and_matches_the_unfused_tick
     finish at different steps (compaction, PE quirk) and run up to position 479 (second key per thread, value loop tail)."""
     feats = eng.encode(W.synthetic_images(32).to(dev))
     outs = {}
-    for tiles in ((4, 4), (2, 8), (4, 16), (0, 4)):
-        e = _engine_with_tick(synth_ckpt, *tiles)
+    for tiles in ((4, 4), (2, 8), (4, 16), (0, 4), (2, 4, "xcd"), (4, 8, "xcd")):
+        e = _engine_with_tick(synth_ckpt, tiles[0], tiles[1], xcd=int(len(tiles) > 2))
         try:
             a = e.decode_greedy(feats)
             b = e.decode_greedy(feats[:5].contiguous(), max_len=480, stop_on_eos=False)
             outs[tiles] = tuple({k: v.cpu() for k, v in o.items() if v is not None} for o in (a, b))
         finally:
             e.close()
-    for tiles in ((2, 8), (4, 16)):
+    for tiles in ((2, 8), (4, 16), (2, 4, "xcd"), (4, 8, "xcd")):      # "xcd": row tiles pinned to XCDs (another grid order)
         for x, y in zip(outs[(4, 4)], outs[tiles]):
             assert torch.equal(x["lengths"], y["lengths"]), f"tiles {tiles}"
             for i, n in enumerate(x["lengths"].tolist()):
@@ -365,8 +365,9 @@ def test_fused_and_unfused_ticks_mix_in_one_job(eng, dev, synth_ckpt):
     res = []
     # (tile, fused_max, branch_rows, branch_max): the last three vary how a tick is cut into parallel branches of rows —
     # one chain, two branches of 96 rows (fused), five of 32, two of 96 on the 8-launch form — which must not change anything
-    for tile, fmax, brows, bmax in ((4, 64, 128, 4), (4, 4096, 0, 1), (0, 0, 0, 1), (2, 128, 128, 4), (4, 128, 32, 8), (0, 0, 96, 2)):
-        e = _engine_with_tick(synth_ckpt, tile, 4, fmax, slots=256, branch_rows=brows, branch_max=bmax)
+    for tile, fmax, brows, bmax, xcd in ((4, 64, 128, 4, 0), (4, 4096, 0, 1, 0), (0, 0, 0, 1, 0), (2, 128, 128, 4, 0), (4, 128, 32, 8, 0),
+                                         (0, 0, 96, 2, 0), (-1, 4096, 0, 1, 1)):
+        e = _engine_with_tick(synth_ckpt, tile, 4, fmax, slots=256, branch_rows=brows, branch_max=bmax, xcd=xcd)
         try:
             res.append({k: v.cpu() for k, v in e.predict(imgs, ref_batch=32).items()})
         finally:
