@@ -3,8 +3,8 @@
 cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rm -f gpurun_out/pixels_parity.json
-timeout 1800 python -m pytest tests -x -q -m gpu > gpurun_out/t_gpu.log 2>&1; echo "pytest rc=$?"
-tail -4 gpurun_out/t_gpu.log | cut -c1-300
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_full20.log 2>&1; echo "bench20 rc=$?"; tail -1 gpurun_out/bench_full20.log | cut -c1-200
+for b in 224 448; do
+  timeout 200 tools/gemm_lab/lab $b 20 - fp16x3 > gpurun_out/r04_gemm_shapes_fp16x3_b$b.txt 2>&1
+  grep -c FAIL gpurun_out/r04_gemm_shapes_fp16x3_b$b.txt
+  python tools/gemm_shapes_report.py gpurun_out/r04_gemm_shapes_fp16x3_b$b.txt | tail -1
+done
