@@ -1238,10 +1238,11 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
         const int cap_step = bound <= 1024 ? 64 : bound <= 2048 ? 128 : 256;
         const int rows_cap = std::min(SL, (std::max(bound, 1) + cap_step - 1) / cap_step * cap_step);
         // the begin kernel scans slot tiles 0 .. highest live tag only (tags are handed out lowest-first): a 20-batch job
-        // keeps it to 768 of the 3072 slots — one pass of its 1024 threads instead of three
+        // keeps it to 1024 of the 3072 slots — one pass of its 1024 threads instead of three; steps of 1024 keep the number of
+        // tick graphs (one per scan range and capacity) small
         int hi_tag = 0;
         for (const Chunk& ck : live) hi_tag = std::max(hi_tag, ck.tag);
-        const int scan = std::min(SL, std::max(((hi_tag + 1) * ROW_TILE + 255) / 256 * 256, rows_cap));
+        const int scan = std::min(SL, std::max(((hi_tag + 1) * ROW_TILE + 1023) / 1024 * 1024, rows_cap));
         hipGraphExec_t exec = nullptr;
         rc = get_tick_graph(h, scan, rows_cap, nullptr, 0, s, &exec);
         if (rc != MNX_OK) return rc;
