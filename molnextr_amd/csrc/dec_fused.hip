@@ -140,11 +140,15 @@ __device__ __forceinline__ float dot32(const f32x4 (&q)[8], const f32x4 (&k)[8])
 // One wave per row at a time (row r on wave r mod NW), lane c owns columns 4c..4c+3. after_issue(): called once, after the
 // first rows' loads have been requested.
 template <int R, int NW, int NP, bool EMB, typename F>
-__device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int n_act, bool writer, float* xs, F&& after_issue) {
+__device__ __forceinline__ bool fused_prologue(const FusedArgs& a, int row0, int n_act, bool writer, float* xs, F&& after_issue) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RW = (R + NW - 1) / NW;     // rows per wave
     constexpr int UB = RW < 2 ? RW : 2;       // rows whose loads are in flight together
-    if (wave >= R) { after_issue(); return; } // (wave-uniform; no barrier inside)
+    if (wave >= R) {                          // (wave-uniform; no barrier inside)
+        if (row0 >= n_act) return false;
+        after_issue();
+        return true;
+    }
     const f32x4 g = ldg4(a.gamma + lane * 4), be = ldg4(a.beta + lane * 4);
     f32x4 bi = {0.f, 0.f, 0.f, 0.f};
     if (NP > 0) bi = ldg4(a.bias_in + lane * 4);
@@ -165,7 +169,10 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int
                 for (int z = 0; z < NP; ++z) p[u][z] = ldg4(a.part_in + (size_t)z * a.part_stride + (size_t)row * 256 + lane * 4);
             }
         }
-        if (i0 == 0) after_issue();           // the kernel's other requests go BEHIND the stream's: first asked, first waited for
+        if (i0 == 0) {                        // the kernel's other requests go BEHIND the stream's: first asked, first waited for
+            if (row0 >= n_act) return false;  // a tile of dummy rows (capacity > alive rows): the whole workgroup leaves
+            after_issue();
+        }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int r = wave + NW * (i0 + u), row = row0 + r;
@@ -179,6 +186,7 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, int row0, int
             *(f32x4*)(xs + r * FXS + lane * 4) = o;
         }
     }
+    return true;
 }
 
 // The same for the kernels with 256 threads per row: the four waves of a row share the partial planes (wave rw sums the
@@ -502,6 +510,8 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     // requests in the order of need: stream + partials, the unit's 64 weights, this thread's key, then the value rows
     ProRegs<EMB ? 0 : 16> pr;
     prologue_issue<R, EMB ? 0 : 16, EMB>(a, row0, pr);
+    if (row0 >= n_act) return;       // a tile of dummy rows (capacity > alive rows): nothing to do. Checked AFTER the stream /
+                                     // plane requests are out (n_active takes a round trip; the weights are not needed before LN)
     typedef LinUnit<96, 4 * R> U;
     const U u = lin_unit<96, 4 * R>();
     float bw[32 * U::CPW];
@@ -573,6 +583,7 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     // needed to ask for them, but whatever is requested first is waited for first)
     ProRegs<8> pr;
     prologue_issue<R, 8, false>(a, row0, pr);
+    if (row0 >= n_act) return;       // a tile of dummy rows
     typedef LinUnit<32, 4 * R> U;
     const U u = lin_unit<32, 4 * R>();
     float bw[32 * U::CPW];
@@ -622,11 +633,11 @@ __global__ __launch_bounds__(256) void dec_fc_kernel(FusedArgs a) {
     const int n_act = a.st->n_active;
     float b1w[64], b2w[64];
     // wave w: chains 2 w, 2 w + 1 of the slice's 64 hidden units (column 64 sl + lane of w1_t); then columns 64 w + lane of w2_t
-    fused_prologue<R, 4, 8, false>(a, row0, n_act, sl == 0, smem + Ld::xs,
-                                   [&]() {
-                                       bload<64>(b1w, a.w1 + (size_t)(64 * wave) * a.dff + FF_SLICE * sl + lane, a.dff);
-                                       bload<64>(b2w, a.w2 + (size_t)(FF_SLICE * sl) * 256 + 64 * wave + lane, 256);
-                                   });
+    const bool alive = fused_prologue<R, 4, 8, false>(a, row0, n_act, sl == 0, smem + Ld::xs, [&]() {
+        bload<64>(b1w, a.w1 + (size_t)(64 * wave) * a.dff + FF_SLICE * sl + lane, a.dff);
+        bload<64>(b2w, a.w2 + (size_t)(FF_SLICE * sl) * 256 + 64 * wave + lane, 256);
+    });
+    if (!alive) return;
     FSTAMP(1);
     FSTAMP(2);
     __syncthreads();

@@ -536,18 +536,25 @@ __global__ __launch_bounds__(1024) void dec_head4_kernel(HeadArgs a) {
     const int4 rv = a.st->rowv[row];
     const int n_act = a.st->n_active;
     const bool valid = col < a.V;
-    // the weights do not depend on the tick: ask for them first (16 per batch, 4 batches)
+    // requests in the order of need: the row's stream + partial planes (wave 0), then — a dummy row (capacity > alive rows)
+    // leaves here, before it asks for 237 KB of weights — the output layer's weights (16 per batch, 4 batches; they are not
+    // needed before the LayerNorm below)
+    f32x4 p[16];
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+        const float* pp = a.part + (size_t)row * 256 + lane * 4;
+        const size_t ps = (size_t)a.part_stride;
+#pragma unroll
+        for (int z = 0; z < 16; ++z) p[z] = *(const f32x4*)(pp + z * ps);
+        xv = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
+    }
+    if (row >= n_act) return;
     float wk[16];
     const float* wp = a.wout_t + (size_t)(64 * kq) * a.VP + (valid ? col : 0);
 #pragma unroll
     for (int k = 0; k < 16; ++k) wk[k] = wp[(size_t)k * a.VP];
     if (wave == 0) {
-        const float* pp = a.part + (size_t)row * 256 + lane * 4;
-        const size_t ps = (size_t)a.part_stride;
-        f32x4 p[16];
-#pragma unroll
-        for (int z = 0; z < 16; ++z) p[z] = *(const f32x4*)(pp + z * ps);
-        f32x4 v = *(const f32x4*)(a.x + (size_t)row * 256 + lane * 4);
+        f32x4 v = xv;
 #pragma unroll
         for (int w = 1; w < 16; w *= 2)
 #pragma unroll
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(1024) void dec_head4_kernel(HeadArgs a) {
         const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.0f / 256.0f);
         const f32x4 o = v * rsqrtf(var + 1e-6f) * *(const f32x4*)(a.gamma + lane * 4) + *(const f32x4*)(a.beta + lane * 4);
         *(f32x4*)(hv + lane * 4) = o;
-        if (row < n_act) *(f32x4*)(a.hidden + ((size_t)rv.x * a.T + rv.y) * 256 + lane * 4) = o;
+        *(f32x4*)(a.hidden + ((size_t)rv.x * a.T + rv.y) * 256 + lane * 4) = o;
     }
     __syncthreads();
     {
@@ -586,7 +593,6 @@ __global__ __launch_bounds__(1024) void dec_head4_kernel(HeadArgs a) {
         lq[kq][col] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    if (row >= n_act) return;
     const int slot = rv.x, t = rv.y;
     float logit = -3.0e38f;
     if (tid < 256 && valid) {
