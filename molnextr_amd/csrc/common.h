@@ -115,6 +115,53 @@ __device__ __forceinline__ f32x4 gelu_fast4(f32x4 x) {
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast4((f32x4){x, x, x, x})[0]; }
 
+// GELU of the split-operand modes (fp32-class results). libm's erff is two divergent branches per value (a polynomial below
+// |x| = 1, an exp-based form above): ~40 VALU + a transcendental + 5 SALU per value, 6 us of a 14 us fc1 epilogue in
+// gemm256x3_kernel. gelu_poly16 is the construction of gelu_fast4 carried to fp32 accuracy: x * Phi(x),
+// Phi = 0.5 + xc * Q(u), xc = clamp(x, +-5.5), u = 2 xc^2 / 5.5^2 - 1, Q the degree-16 Chebyshev fit of (Phi(x) - 0.5) / x in
+// monomials of u, every step one FMA (packed: two values per instruction). Against the exact function its error is
+// <= 1.3e-7 max(1, |x|) (rms 1.6e-8) — the formula the reference evaluates, 0.5 x (1 + erf(x / sqrt 2)) in fp32 with a
+// correctly rounded erf, has 1.1e-7 max(1, |x|) (rms 1.2e-8): tests/test_device_math.py checks both numbers. x < -5.5 returns
+// -5.5 Phi(-5.5) = -1.0e-7 (exact: -> 0). Every split-mode epilogue (gemm256.hip, gemm.hip) uses the same function, so an
+// image's features stay independent of which kernel a row lands in.
+#ifndef MNX_GELU_POLY
+#define MNX_GELU_POLY 0
+#endif
+__device__ __forceinline__ f32x4 gelu_poly16(f32x4 x) {
+    f32x4 xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -5.5f, 5.5f);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -5.5f, 5.5f);
+    xc[2] = __builtin_amdgcn_fmed3f(x[2], -5.5f, 5.5f);
+    xc[3] = __builtin_amdgcn_fmed3f(x[3], -5.5f, 5.5f);
+    const f32x4 u = xc * xc * 6.611570248e-02f - 1.0f;
+    f32x4 q = u * 1.1807999527e-04f + -2.8567631769e-04f;
+    q = q * u + 1.8391666569e-04f;
+    q = q * u + -3.5675461462e-04f;
+    q = q * u + 1.4074264731e-03f;
+    q = q * u + -2.6587023769e-03f;
+    q = q * u + 4.0741296491e-03f;
+    q = q * u + -6.6506783549e-03f;
+    q = q * u + 1.0468637002e-02f;
+    q = q * u + -1.5062524020e-02f;
+    q = q * u + 2.0307316921e-02f;
+    q = q * u + -2.6036151485e-02f;
+    q = q * u + 3.2076909454e-02f;
+    q = q * u + -3.8793793902e-02f;
+    q = q * u + 4.7737334640e-02f;
+    q = q * u + -6.4172314669e-02f;
+    q = q * u + 1.2855193299e-01f;
+    f32x4 xo;
+    xo[0] = fmaxf(x[0], -5.5f); xo[1] = fmaxf(x[1], -5.5f); xo[2] = fmaxf(x[2], -5.5f); xo[3] = fmaxf(x[3], -5.5f);
+    return xo * (xc * q + 0.5f);
+}
+__device__ __forceinline__ f32x4 gelu_split4(f32x4 v) {
+#if MNX_GELU_POLY
+    return gelu_poly16(v);
+#else
+    return (f32x4){gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+#endif
+}
+
 // bijective XCD-aware remap of a linear workgroup id (guide T1): consecutive ids land on the same XCD/L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int NX = 8;

@@ -73,6 +73,7 @@ struct FusedArgs {
     // dec_fa
     const float *wqkv, *bqkv, *wo;     // wqkv_t [256][768], wo_t [256][256]
     float *kcache, *vcache;  // this layer's self K / V cache [slots, heads, T, 32]
+    float* qbuf;             // mid form: the scaled queries [rows, 256] handed from dec_ma_kernel to dec_mb_kernel
     const float *emb, *pe;
     // dec_fb
     const float *wq2, *bq2, *wo2;      // wq2_t, wo2_t [256][256]
@@ -139,11 +140,11 @@ __device__ __forceinline__ float dot32(const f32x4 (&q)[8], const f32x4 (&k)[8])
 // ---- stage prologue: x = stream (+ tree(partials) + bias) or embedding; stream out; LayerNorm(eps 1e-6) -> xs[r][FXS] ----
 // One wave per row at a time (row r on wave r mod NW), lane c owns columns 4c..4c+3. after_issue(): called once, after the
 // first rows' loads have been requested.
-template <int R, int NW, int NP, bool EMB, typename F>
+template <int R, int NW, int NP, bool EMB, int UBMAX = 2, typename F>
 __device__ __forceinline__ bool fused_prologue(const FusedArgs& a, int row0, int n_act, bool writer, float* xs, F&& after_issue) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RW = (R + NW - 1) / NW;     // rows per wave
-    constexpr int UB = RW < 2 ? RW : 2;       // rows whose loads are in flight together
+    constexpr int UB = RW < UBMAX ? RW : UBMAX;   // rows whose loads are in flight together
     if (wave >= R) {                          // (wave-uniform; no barrier inside)
         if (row0 >= n_act) return false;
         after_issue();
@@ -375,12 +376,16 @@ __device__ __forceinline__ void attn_prefetch_v(AttnPre<VP>& pre, const float* V
 
 struct AttnLds { float *qs, *ks, *vs, *ps, *cs, *redm, *reds, *po; };   // per-kernel LDS arrays, all [R][...]
 
-template <int R, bool CROSS, int VP, int PS>
+// MODE 0: self-attention, this step's key / value (position ncache) in LDS (dec_fa_kernel); 1: cross-attention over ncache
+// memory rows; 2: self-attention with every key / value in the cache, ncache = t + 1 (dec_mb_kernel: the row of this step
+// was appended by the launch before). 0 and 2 evaluate the same chains on the same numbers.
+template <int R, int MODE, int VP, int PS>
 __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* Kb, const float* Vb, int ncache, const AttnLds& m,
                                           const FusedArgs& a) {
+    constexpr bool CROSS = MODE == 1, NEWLDS = MODE == 0;
     const int rl = threadIdx.x >> 8, rt = threadIdx.x & 255, lane = rt & 63, rw = rt >> 6, kg = lane >> 3, dq = lane & 7;
     float* ps = m.ps + rl * PS;
-    const int nkeys = CROSS ? ncache : ncache + 1;
+    const int nkeys = NEWLDS ? ncache + 1 : ncache;
     f32x4 q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(m.qs + rl * 32 + i * 4);
@@ -400,7 +405,7 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
                 for (int i = 0; i < 8; ++i) kv[i] = ldg4(Kb + (size_t)key * 32 + i * 4);
                 s = dot32(q, kv);
             }
-        } else if (!CROSS && key == ncache) {
+        } else if (NEWLDS && key == ncache) {
             f32x4 kv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(m.ks + rl * 32 + i * 4);
@@ -435,7 +440,7 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
             const float pk = ps[key];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaf(pre.v[i][e], pk, o[e]);
-        } else if (!CROSS && key == ncache) {
+        } else if (NEWLDS && key == ncache) {
             const f32x4 vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
             const float pk = ps[key];
 #pragma unroll
@@ -445,7 +450,7 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
 #pragma unroll 8
     for (int key = rw * 8 + kg + 32 * VP; key < nkeys; key += 32) {
         f32x4 vv;
-        if (!CROSS && key == ncache) vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
+        if (NEWLDS && key == ncache) vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
         else vv = ldg4(Vb + (size_t)key * 32 + dq * 4);
         const float pk = ps[key];
 #pragma unroll
@@ -554,12 +559,112 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     FSTAMP(6);
     const AttnLds m = {smem + Ld::qs, smem + Ld::ks, smem + Ld::vs, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm,
                        smem + Ld::reds, smem + Ld::po};
-    attn_rows<R, false, VP, PS_SELF>(pre, Kb, Vb, rv.y, m, a);
+    attn_rows<R, 0, VP, PS_SELF>(pre, Kb, Vb, rv.y, m, a);
     if (R >= 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);   // 128 registers per thread: not earlier
     __syncthreads();
     FSTAMP(10);
     slice_mfma_store<32, FHS, R>(smem + Ld::cs, bo, a.part_out + (size_t)h * a.part_stride, row0, n_act);
     FSTAMP(11);
+}
+
+// =============================================================================================
+// Mid form (ticks of more than dec_fused_max rows, round 5): dec_fa cut in two where its row tiles want different sizes.
+// dec_fa re-reads the head's 96 KB of wqkv and the 17 KB-per-row stream + partial planes for every 2-4 rows: 1.1 us per row and
+// tick against the 0.4 of decoder.hip's 32-row linears — at 256+ rows that is more bytes than the K / V rows the
+// attention is there for. The linear half wants MANY rows per workgroup, the attention half many (row, head) workgroups:
+//   dec_ma_kernel  grid (head, 16-row tile), 512 threads: stream + partials -> LN1 -> q | k | v of the head; q (scaled) ->
+//                  qbuf, k / v -> the slot's cache. The weights are read once per 16 rows.
+//   dec_mb_kernel  grid (head, R-row tile), 256 R threads: q from qbuf, ALL keys / values from the cache (the row of this
+//                  step included) -> attention -> Wo partial: dec_fa's second half.
+// dec_fb / dec_fc follow unchanged (their weights are 2-4x lighter per row). Every chain, tree and softmax order is dec_fa's:
+// a row's numbers are bit-identical in both forms — which form a tick takes (mnx_predict picks by capacity, and the capacity
+// follows host timing) cannot be seen in the results.
+// =============================================================================================
+struct MaLds {
+    static constexpr int R = 16;
+    static constexpr int xs = 0, red = xs + R * FXS;              // red [8][R][96 + 4]
+    static constexpr int total = red + 8 * R * 100;               // 67.8 KB
+};
+template <int R> struct MbLds {
+    static constexpr int qs = 0, cs = qs + R * 32;
+    static constexpr int redm = cs + R * FHS, reds = redm + R * 4, po = reds + R * 4;
+    static constexpr int ps = po + R * 128;
+    static constexpr int total = ps + R * PS_SELF;                // 11.3 KB at R = 4
+};
+
+template <bool EMB>
+__global__ __launch_bounds__(512) void dec_ma_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef MaLds Ld;
+    constexpr int R = Ld::R;
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x;
+    const int row0 = a.row_base + (int)blockIdx.y * R;
+    const int n_act = a.st->n_active;
+    typedef LinUnit<96, 8> U;                             // 2 column blocks x 8 chains on 8 waves: 2 chains per wave
+    const U u = lin_unit<96, 8>();
+    static_assert(U::CPW == 2, "two chains per wave");
+    // the lane's column of wqkv_t (q | k | v of head h) for its two chains: the first chain's 32 weights are requested behind
+    // the first rows' stream / plane loads, the second chain's once the prologue has released its 64 plane registers (they
+    // arrive while the first chain runs) — requested all at once the kernel spilled
+    const int wc = u.valid ? u.n : 0;
+    const float* wcol = a.wqkv + (size_t)(32 * u.kc0) * 768 + (wc >> 5) * 256 + 32 * h + (wc & 31);
+    float bw0[32], bw1[32];
+    const bool alive = fused_prologue<R, 8, EMB ? 0 : 16, EMB, 1>(a, row0, n_act, h == 0, smem + Ld::xs, [&]() {
+        if (u.active) bload<32>(bw0, wcol, 768);
+    });
+    if (!alive) return;
+    if (u.active) bload<32>(bw1, wcol + (size_t)32 * 768, 768);
+    float bw[64];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { bw[k] = bw0[k]; bw[32 + k] = bw1[k]; }
+    __syncthreads();                                      // xs complete
+    lin256_chains<96, 8, R>(u, smem + Ld::xs, bw, smem + Ld::red);
+    __syncthreads();
+    for (int idx = tid; idx < R * 96; idx += 512) {
+        const int r = idx / 96, c = idx - r * 96, part = c >> 5, d = c & 31;
+        const float v = red_get<96, R>(smem + Ld::red, r, c) + a.bqkv[part * 256 + 32 * h + d];
+        const int row = row0 + r;
+        if (row >= n_act) continue;
+        if (part == 0) {
+            a.qbuf[(size_t)row * 256 + 32 * h + d] = v * QSCALE;
+        } else {
+            const int4 rr = a.st->rowv[row];
+            float* cache = part == 1 ? a.kcache : a.vcache;
+            cache[(((size_t)rr.x * a.heads + h) * a.T + rr.y) * 32 + d] = v;
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256 * R) void dec_mb_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef MbLds<R> Ld;
+    constexpr int VP = R >= 4 ? 4 : 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rt = tid & 255;
+    const int h = blockIdx.x;
+    const int row0 = a.row_base + (int)blockIdx.y * R;
+    const int4 rv = a.st->rowv[row0 + (tid >> 8)];       // {slot, t, prev_tok, rank}; dummy rows: slot 0, t 0
+    const int n_act = a.st->n_active;
+    const int nk = rv.y + 1;                             // keys of the row: positions 0 .. t
+    const float* Kb = a.kcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
+    const float* Vb = a.vcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
+    AttnPre<VP> pre;
+    attn_prefetch_k<VP>(pre, Kb, nk);
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+    if (rt < 8) qv = ldg4(a.qbuf + (size_t)(row0 + (tid >> 8)) * 256 + 32 * h + rt * 4);
+    float bo[32];                                        // the head's slice of wo_t, columns 64 wave + lane (waves 0..3)
+    if (R < 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);
+    attn_prefetch_v<VP>(pre, Vb, nk);
+    if (row0 >= n_act) return;                           // a tile of dummy rows (uniform per workgroup)
+    if (rt < 8) *(f32x4*)(smem + Ld::qs + (tid >> 8) * 32 + rt * 4) = qv;
+    __syncthreads();
+    const AttnLds m = {smem + Ld::qs, nullptr, nullptr, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm, smem + Ld::reds,
+                       smem + Ld::po};
+    attn_rows<R, 2, VP, PS_SELF>(pre, Kb, Vb, nk, m, a);
+    if (R >= 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);   // 128 registers per thread: not earlier
+    __syncthreads();
+    slice_mfma_store<32, FHS, R>(smem + Ld::cs, bo, a.part_out + (size_t)h * a.part_stride, row0, n_act);
 }
 
 // =============================================================================================
@@ -611,7 +716,7 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     FSTAMP(6);
     const AttnLds m = {smem + Ld::qs, nullptr, nullptr, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm, smem + Ld::reds,
                        smem + Ld::po};
-    attn_rows<R, true, VP, PS_CROSS>(pre, Kb, Vb, a.S, m, a);
+    attn_rows<R, 1, VP, PS_CROSS>(pre, Kb, Vb, a.S, m, a);
     __syncthreads();
     FSTAMP(10);
     slice_mfma_store<32, FHS, R>(smem + Ld::cs, bo, a.part_out + (size_t)h * a.part_stride, row0, n_act);
@@ -693,6 +798,10 @@ hipError_t dec_fused_init() {
     }
     hipError_t e = fused_init_ab<2>();
     if (e == hipSuccess) e = fused_init_ab<4>();
+    if (e == hipSuccess) e = opt_in(dec_ma_kernel<true>, MaLds::total * 4);
+    if (e == hipSuccess) e = opt_in(dec_ma_kernel<false>, MaLds::total * 4);
+    if (e == hipSuccess) e = opt_in(dec_mb_kernel<2>, MbLds<2>::total * 4);
+    if (e == hipSuccess) e = opt_in(dec_mb_kernel<4>, MbLds<4>::total * 4);
     if (e == hipSuccess) e = opt_in(dec_fc_kernel<4>, FcLds<4>::total * 4);
     if (e == hipSuccess) e = opt_in(dec_fc_kernel<8>, FcLds<8>::total * 4);
     if (e == hipSuccess) e = opt_in(dec_fc_kernel<16>, FcLds<16>::total * 4);
@@ -701,7 +810,7 @@ hipError_t dec_fused_init() {
 
 // R: rows per workgroup of the two attention stages (256 threads per row); RC: rows per workgroup of the feed-forward stage
 template <int R, int RC>
-static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, int xcd, hipStream_t s) {
+static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, int xcd, bool mid, hipStream_t s) {
     const int D = 256, H = w.heads, T = b.T;
     int stage = 0;      // stage k reads stream k & 1 and partial buffer (k - 1) & 1, writes stream / partials (k + 1) & 1 / k & 1
     float* xb[2] = {b.x, b.x2};
@@ -711,7 +820,8 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
     a.mem_stride = (long long)b.S * w.layers * 2 * D;
     a.stamps = g_stamps;
     a.row_base = row_base;
-    a.xcd = (xcd && rows % 32 == 0) ? 1 : 0;
+    a.xcd = (xcd && !mid && rows % 32 == 0) ? 1 : 0;
+    a.qbuf = b.q;
     for (int l = 0; l < w.layers; ++l) {
         const DecLayerW& Lw = w.L[l];
         // ---- self-attention block
@@ -722,7 +832,12 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
         a.kcache = b.self_k + (size_t)l * b.slots * H * T * 32;
         a.vcache = b.self_v + (size_t)l * b.slots * H * T * 32;
         const dim3 gab = a.xcd ? dim3(rows / R, H) : dim3(H, rows / R);
-        if (l == 0) hipLaunchKernelGGL((dec_fa_kernel<R, true>), gab, dim3(256 * R), FaLds<R>::total * 4, s, a);
+        if (mid) {      // the linear half on 16-row tiles, then the attention half on R-row tiles
+            const dim3 gma(H, rows / MaLds::R);
+            if (l == 0) hipLaunchKernelGGL((dec_ma_kernel<true>), gma, dim3(512), MaLds::total * 4, s, a);
+            else hipLaunchKernelGGL((dec_ma_kernel<false>), gma, dim3(512), MaLds::total * 4, s, a);
+            hipLaunchKernelGGL((dec_mb_kernel<R>), gab, dim3(256 * R), MbLds<R>::total * 4, s, a);
+        } else if (l == 0) hipLaunchKernelGGL((dec_fa_kernel<R, true>), gab, dim3(256 * R), FaLds<R>::total * 4, s, a);
         else hipLaunchKernelGGL((dec_fa_kernel<R, false>), gab, dim3(256 * R), FaLds<R>::total * 4, s, a);
         ++stage;
         // ---- context-attention block
@@ -742,21 +857,23 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
     }
 }
 
-// The 3 x layers kernels of a greedy tick for `rows` rows of capacity (a multiple of 32). row_tile = 10 * R + log2(RC)...:
-// encoded as R * 100 + RC (R in {2, 4}: rows per attention workgroup; RC in {4, 8, 16}: rows per feed-forward workgroup).
+// The 3 (mid form: 4) x layers kernels of a greedy tick for `rows` rows of capacity (a multiple of 16). row_tile is encoded as
+// R * 100 + RC (R in {2, 4}: rows per attention workgroup; RC in {4, 8, 16}: rows per feed-forward workgroup), + 1000: row tiles
+// pinned to XCDs, + 2000: the mid form.
 // Returns the stream buffer and the partial buffer the head has to sum (16 partials of the last w_2 + its bias).
 hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, int row_base, int rows, int row_tile, hipStream_t s,
                                     const float** x_final, const float** part_final) {
-    const int xcd = row_tile / 1000;         // 1000 + 100 R + RC: XCD-local row tiles (FusedArgs::xcd)
+    const bool mid = row_tile >= 2000;       // 2000 + 100 R + RC: the mid form (dec_ma + dec_mb instead of dec_fa)
+    const int xcd = (row_tile / 1000) & 1;   // 1000 + 100 R + RC: XCD-local row tiles (FusedArgs::xcd)
     row_tile %= 1000;
     if (w.dff != 16 * FF_SLICE || w.heads != 8 || b.T + 1 > PS_SELF || b.S > PS_CROSS || (rows % 16) || !b.fpart)
         return hipErrorInvalidValue;
     switch (row_tile) {
-        case 204: fused_layers<2, 4>(w, b, row_base, rows, xcd, s); break;
-        case 208: fused_layers<2, 8>(w, b, row_base, rows, xcd, s); break;
-        case 404: fused_layers<4, 4>(w, b, row_base, rows, xcd, s); break;
-        case 408: fused_layers<4, 8>(w, b, row_base, rows, xcd, s); break;
-        case 416: fused_layers<4, 16>(w, b, row_base, rows, xcd, s); break;
+        case 204: fused_layers<2, 4>(w, b, row_base, rows, xcd, mid, s); break;
+        case 208: fused_layers<2, 8>(w, b, row_base, rows, xcd, mid, s); break;
+        case 404: fused_layers<4, 4>(w, b, row_base, rows, xcd, mid, s); break;
+        case 408: fused_layers<4, 8>(w, b, row_base, rows, xcd, mid, s); break;
+        case 416: fused_layers<4, 16>(w, b, row_base, rows, xcd, mid, s); break;
         default: return hipErrorInvalidValue;
     }
     const int stages = 3 * w.layers;

@@ -865,7 +865,7 @@ hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_tab
     do {                                                                                                                \
         hipError_t e_ = attn_lds_opt_in<window_attn_pipe_kernel<TT, MASKED>>();                                           \
         if (e_ != hipSuccess) return e_;                                                                                \
-        hipLaunchKernelGGL((window_attn_pipe_kernel<TT, MASKED>), dim3((NITEMS) < 512 ? (NITEMS) : 512), dim3(576), WA_LDS, s,  \
+        hipLaunchKernelGGL((window_attn_pipe_kernel<TT, MASKED>), dim3((NITEMS) < 2 * persistent_cus() ? (NITEMS) : 2 * persistent_cus()), dim3(576), WA_LDS, s,  \
                            (const TT*)qkv16, qkv_lo, rel_table, (TT*)out16, out_lo, H, W, C, heads, shift, CLS, NITEMS); \
     } while (0)
             if (dtype == MNX_DT_F16X3) {

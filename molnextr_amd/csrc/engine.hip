@@ -99,6 +99,12 @@ struct mnx_engine {
     // the two attention stages (256 threads per row), dec_tile_ff rows in the feed-forward stage; larger ticks keep the
     // 8-launches-per-layer kernels of decoder.hip (knobs MNX_DEC_TILE, MNX_DEC_TILE_FF, MNX_DEC_FUSED_MAX)
     int dec_tile = -1, dec_tile_ff = 4, dec_fused_max = 128;
+    // ticks of more than dec_fused_max and up to dec_mid_max rows run the MID form (dec_fused.hip: dec_fa cut into a 16-row
+    // linear launch and an attention launch, 4 launches per layer; bit-identical to the fused form, so that the capacity the
+    // host happens to pick — it follows poll timing — is invisible in the results up to dec_mid_max rows); beyond that the
+    // 8-launches-per-layer kernels of decoder.hip, whose 32-row linears move the fewest bytes per row (MNX_DEC_MID_MAX;
+    // 4096 = every capacity: bit-reproducible jobs of any size, slower at >= 1024 rows)
+    int dec_mid_max = 640;
     int dec_xcd = 0;           // fused tick: row tiles pinned to XCDs so that a row's partial planes stay in one L2 (MNX_DEC_XCD)
     // a tick of more than dec_branch_rows rows can be enqueued as up to dec_branch_max BRANCHES of rows on parallel branches
     // of the tick graph (rows are independent through the whole stack). OFF by default (0): measured, the branches of a
@@ -315,15 +321,31 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->device = device;
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
+    // MNX_ENC_CUS=n (default 256): the encoder's persistent kernels (gemm256x3_kernel: one 150 KB-LDS workgroup per CU for the
+    // length of a launch; window_attn_pipe_kernel: two) are launched on n workgroups (2 n), so that 256 - n CUs stay free for
+    // the decode stream's kernels while they run (co-residency without a CU mask). Process-wide.
+    if (const char* e = getenv("MNX_ENC_CUS")) {
+        const int n = atoi(e);
+        if (n < 64 || n > 256) {
+            g_create_error = "mnx_create: MNX_ENC_CUS must be 64..256";
+            delete h;
+            return MNX_ERR_INVALID_ARG;
+        }
+        set_persistent_cus(n);
+    }
     if (const char* e = getenv("MNX_DEC_BRANCH_ROWS")) h->dec_branch_rows = atoi(e);
     if (const char* e = getenv("MNX_DEC_BRANCH_MAX")) h->dec_branch_max = std::max(1, std::min(MAX_TICK_BRANCHES, atoi(e)));
     if (const char* e = getenv("MNX_DEC_XCD")) h->dec_xcd = atoi(e) != 0;
     if (const char* e = getenv("MNX_DEC_TILE")) h->dec_tile = atoi(e);              // 0: never use the fused tick
     if (const char* e = getenv("MNX_DEC_TILE_FF")) h->dec_tile_ff = atoi(e);
     if (const char* e = getenv("MNX_DEC_FUSED_MAX")) h->dec_fused_max = atoi(e);    // largest capacity that runs fused
+    if (const char* e = getenv("MNX_DEC_MID_MAX")) h->dec_mid_max = atoi(e);        // largest capacity that runs the mid form
+    // dec_fused.hip instantiates (attention rows, feed-forward rows) = (2, 4) (2, 8) (4, 4) (4, 8) (4, 16): 16-row feed-forward
+    // tiles only go with 4-row attention tiles (auto picks 2 rows up to 64 rows of capacity) — refused here, not at the first tick
     if ((h->dec_tile != -1 && h->dec_tile != 0 && h->dec_tile != 2 && h->dec_tile != 4) ||
-        (h->dec_tile_ff != 4 && h->dec_tile_ff != 8 && h->dec_tile_ff != 16)) {
-        g_create_error = "mnx_create: MNX_DEC_TILE must be -1 (auto), 0, 2 or 4 and MNX_DEC_TILE_FF 4, 8 or 16";
+        (h->dec_tile_ff != 4 && h->dec_tile_ff != 8 && h->dec_tile_ff != 16) ||
+        (h->dec_tile_ff == 16 && h->dec_tile != 4 && h->dec_tile != 0)) {
+        g_create_error = "mnx_create: MNX_DEC_TILE must be -1 (auto), 0, 2 or 4 and MNX_DEC_TILE_FF 4, 8 or 16 (16 only with MNX_DEC_TILE=4)";
         delete h;
         return MNX_ERR_INVALID_ARG;
     }
@@ -754,7 +776,11 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
 static int tick_tile(const mnx_engine* h, int rows) {
     const mnx_config& c = h->cfg;
     if (c.dec_ff != 1024 || c.dec_heads != 8 || c.dec_dim != 256 || c.max_len + 1 > 512 || h->db.S > 160) return 0;
-    if (h->dec_tile == 0 || rows > h->dec_fused_max || rows % 16) return 0;
+    if (h->dec_tile == 0 || rows % 16) return 0;
+    if (rows > h->dec_fused_max) {      // mid form: 4-row attention tiles, 16-row feed-forward tiles
+        if (rows > h->dec_mid_max) return 0;
+        return 2000 + 100 * 4 + 16;
+    }
     const int r = h->dec_tile > 0 ? h->dec_tile : (rows <= 64 ? 2 : 4);
     return (h->dec_xcd ? 1000 : 0) + 100 * r + h->dec_tile_ff;
 }

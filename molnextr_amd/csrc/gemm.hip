@@ -126,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue_split(f32x4 (&acc)[BN / 32][4], ch
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 v = acc[nt][mt] * sp.oscale + b4;
-            if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            if (EPI == EPI_GELU_16) v = gelu_split4(v);
             split16x4<T>(v, hi[nt][mt], lo[nt][mt]);
         }
     }
@@ -482,9 +482,9 @@ hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* 
 // rows that launch_gemm16 gives to gemm256x3_kernel (the rest goes to the 128x128 kernel); 0 = none
 static int x3_main_rows(int dtype, int epi, int M, int N, int K, int terms) {
     if (!dt_split(dtype) || terms != 3 || !gemm256x3_supports(dtype, epi, M, N, K)) return 0;
-    const int tn = N / 256, tm = M / 256, tiles = tm * tn;
+    const int tn = N / 256, tm = M / 256, tiles = tm * tn, cus = persistent_cus();
     int tm_main = tm;
-    if (tiles % 256 != 0 && (tiles % 256) * 10 < 256 * 8) tm_main = (tiles / 256) * 256 / tn;
+    if (tiles % cus != 0 && (tiles % cus) * 10 < cus * 8) tm_main = (tiles / cus) * cus / tn;
     return tm_main * 256;
 }
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
                 v4 o4;
                 if (SPLIT) {
                     f32x4 v = acc[mt][nt] * sp.oscale + b4[nt];
-                    if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                    if (EPI == EPI_GELU_16) v = gelu_split4(v);
                     split16x4<T>(v, o4, lo[nt]);
                 } else {
                     f32x4 v = acc[mt][nt] + b4[nt];
@@ -328,6 +328,49 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 constexpr int X3_BIAS = 1;                                 // one 4-byte-per-lane DMA per wave per tile (its 64 bias values)
 constexpr int X3_LDS = P_LDS + 8 * 256;                    // + a 256-byte bias patch per wave
 
+// fp32-output epilogue form:
+//   0  straight from the accumulators with compiler-tracked loads / stores (rounds 3-4): the generated code is ONE chain per
+//      16-row slab — 4 residual loads, s_waitcnt vmcnt(0) (which also waits for the previous slab's stores to be
+//      acknowledged), 4 stores — i.e. 4 KiB in flight per wave: 20 us per 256x256 tile;
+//   1  the same lane -> element mapping, residual loads and stores through inline asm (scalar tile base + 32-bit lane
+//      offset), retired by counted vmcnt: the residual of FOUR slabs in flight per wave (16 KiB; the registers are the
+//      main loop's operand fragments, dead in the epilogue), stores never waited for;
+//   2  as 1, and every access a whole 128-byte line: the slab goes through the wave's staging patch (two halves of 32
+//      columns) into the row-major lane mapping of the 16-bit epilogue — 8 rows x 128 B per instruction instead of
+//      16 rows x 64 B —, the residual is loaded in that mapping directly.
+// The arithmetic per element is the same in all three: (oscale * acc + bias) + residual.
+#ifndef MNX_X3_EPI32
+#define MNX_X3_EPI32 2
+#endif
+// tools/gemm_lab ablations of the six-phase loop (results are garbage by design; what is timed is what remains):
+//   bit 0  no ring refills after the prologue            bit 1  no MFMAs (fragments still read)
+//   bit 2  no epilogue at all (accumulators zeroed)       bit 3  no fragment reads after the first K-tile
+//   bit 4  per-workgroup clock stamps (s_memtime = shader cycles, s_memrealtime = 100 MHz) -> x3_lab_stamps
+//   bit 5  epilogue arithmetic and LDS staging without its global loads / stores
+#ifndef MNX_X3_LAB
+#define MNX_X3_LAB 0
+#endif
+#if MNX_X3_LAB & 16
+__device__ unsigned long long x3_lab_stamps[256 * 8];
+#endif
+// tools/gemm_lab: cohorts of workgroups (cohort = (workgroup / 8) % 4, every XCD has all four) start MNX_X3_STAGGER x 10 ns
+// apart — are the tile epilogues of 256 workgroups in lockstep bound by what the chip can absorb at once?
+#ifndef MNX_X3_STAGGER
+#define MNX_X3_STAGGER 0
+#endif
+
+// fp32 epilogue forms 1 / 2: vector-memory operations younger than the residual loads of slab mt when they are waited for
+// (4 loads + 4 stores per slab, four slabs of loads in flight): 12 16 20 24 24 20 16 12
+__device__ __forceinline__ void x3_wait_younger(int mt) {
+    const int y = mt < 4 ? 12 + 4 * mt : 12 + 4 * (7 - mt);
+    switch (y) {
+        case 12: wait_vm<12>(); break;
+        case 16: wait_vm<16>(); break;
+        case 20: wait_vm<20>(); break;
+        default: wait_vm<24>(); break;
+    }
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cv,
                                                          const float* __restrict__ bias, const float* resid, int M, int N,
@@ -350,6 +393,12 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     const int total_kt = my_tiles * nk;
     const long a_lo_b = (long)sp.a_lo * 2, w_lo_b = (long)sp.w_lo * 2;
     enum { S_AH0 = 0, S_AH1 = 1, S_AL0 = 2, S_AL1 = 3, S_WH0 = 4, S_WH1 = 5, S_WL0 = 6, S_WL1 = 7 };
+    constexpr bool LAB_NOFILL = (MNX_X3_LAB & 1) != 0, LAB_NOMFMA = (MNX_X3_LAB & 2) != 0, LAB_NOEPI = (MNX_X3_LAB & 4) != 0,
+                   LAB_NOREAD = (MNX_X3_LAB & 8) != 0, LAB_NOGLB = (MNX_X3_LAB & 32) != 0;
+#if MNX_X3_LAB & 16
+    unsigned long long lab_c0 = 0, lab_r0 = 0, lab_epi = 0;
+    if (lane == 0) { lab_c0 = __builtin_readcyclecounter(); lab_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
     // DMA addressing: a wave fills two 1 KiB pieces (8 rows x 128 B) of every slot. The lane part of a piece's source
     // offset is the same for both 64-row halves of A (both 32-row halves of W): the half is a scalar addend on the base.
@@ -404,6 +453,13 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#if MNX_X3_STAGGER
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * MNX_X3_STAGGER;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     int m0, n0;
     tile_origin(0, m0, n0);
     load_bias(n0);
@@ -454,6 +510,16 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     // the 32 MFMAs of one phase: rows [mb*16, mb*16 + 64) of the wave tile += af . (b0 | b1)
     auto mfma_block = [&](auto mb_c) {
         constexpr int mb = decltype(mb_c)::value;
+        if (LAB_NOMFMA) {       // the fragments still have to arrive in registers
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[i][ks]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b0[j][ks]), "v"(b1[j][ks]));
+            }
+            return;
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -470,10 +536,21 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     using MB0 = std::integral_constant<int, 0>;
     using MB4 = std::integral_constant<int, 4>;
     auto epilogue = [&]() {
+        if (LAB_NOEPI) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    asm volatile("" ::"v"(acc[mt][nt]));
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            return;
+        }
         f32x4 b4[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) b4[nt] = *(const f32x4*)(bias_s + nt * 16 + fg * 4);
         if (!OUT16) {
+#if MNX_X3_EPI32 == 0
             // ---- fp32 output (+ in-place fp32 residual): straight from the accumulators. A lane owns 4 consecutive columns
             // of row fr of every 16-row slab: 16-byte accesses, the 4 lane groups of a row cover 64 contiguous bytes. Every
             // element is read and written by the same lane, so C may alias the residual. The loads and stores are ordinary
@@ -489,14 +566,120 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
                     v[nt] = acc[mt][nt] * sp.oscale + b4[nt];
                     acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                if (EPI == EPI_RESID_F32) {
+                if (EPI == EPI_RESID_F32 && !LAB_NOGLB) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) v[nt] += *(const f32x4*)(rp + (size_t)mt * 16 * N + nt * 16);
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) *(f32x4*)(cp + (size_t)mt * 16 * N + nt * 16) = v[nt];
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (LAB_NOGLB) asm volatile("" ::"v"(v[nt]));
+                    else *(f32x4*)(cp + (size_t)mt * 16 * N + nt * 16) = v[nt];
+                }
             }
             return;
+#else
+            // ---- fp32 output (+ in-place fp32 residual), forms 1 / 2 (see MNX_X3_EPI32 above). Residual loads and stores are
+            // inline asm on a scalar base (the wave's 128 x 64 block of the tile) + a 32-bit lane offset; no compiler-tracked
+            // vector-memory operation exists in this epilogue, so the compiler adds no wait of its own. In-order retirement:
+            // the sequence of a wave is L0 L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 | S5 | S6 | S7 (L = 4 residual loads
+            // of a slab, S = its 4 stores); the residual of slab mt is complete once at most x3_epi_younger(mt) younger
+            // operations are outstanding. Every element is read and written by the same lane (C may alias the residual), and
+            // a slab's loads are issued after the stores of the slab four before it, whose rows they do not touch.
+            constexpr bool RES = (EPI == EPI_RESID_F32);
+            // ONE scalar base per array for the whole epilogue (the wave's 128 x 64 block of the tile); everything that changes
+            // from slab to slab is in the 32-bit lane offset (a VALU result: its hand-over to a vector-memory instruction is
+            // interlocked by the hardware). Reason: gfx950 requires wait states between a SALU write of an SGPR and a
+            // vector-memory instruction that uses it as its address base, and the compiler's hazard recognizer does not look
+            // into inline asm — the first build of this epilogue re-derived the base per slab with s_add / s_addc right in
+            // front of the asm stores and 1.4 % of the words landed elsewhere. The s_nop below covers the one place where the
+            // bases are produced. The stores carry their own s_nop: a VALU write of the data registers of a 16-byte store in
+            // the very next instruction is the other hazard the compiler cannot see (0.2 % wrong words in the bias-only form).
+            const size_t wbase = ((size_t)(m0 + wr * 128) * N + n0 + wc * 64) * 4;
+            const char* cb = (const char*)Cv + wbase;
+            const char* rb = RES ? (const char*)resid + wbase : cb;
+            asm volatile("s_nop 4" ::"s"(cb), "s"(rb));
+            const unsigned slab_b = (unsigned)N * 64u;                // 16 rows
+#define MNX_X3_LD1(dst, off, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=&v"(dst) : "v"(off), "s"(rb) : "memory")
+#define MNX_X3_ST1(src, off, imm) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm "\n\ts_nop 1" ::"v"(off), "v"(src), "s"(cb) : "memory")
+#if MNX_X3_EPI32 == 1
+            const unsigned voff = (unsigned)((fr * N + fg * 4) * 4);          // row fr, 16 bytes at column 4 fg (+ 16 nt)
+#define MNX_X3_LD(d, mt)                                                                                                  \
+    do {                                                                                                                  \
+        const unsigned o_ = voff + (unsigned)(mt) * slab_b;                                                               \
+        MNX_X3_LD1(d[0], o_, 0); MNX_X3_LD1(d[1], o_, 64); MNX_X3_LD1(d[2], o_, 128); MNX_X3_LD1(d[3], o_, 192);         \
+    } while (0)
+#define MNX_X3_ST(v, mt)                                                                                                  \
+    do {                                                                                                                  \
+        const unsigned o_ = voff + (unsigned)(mt) * slab_b;                                                               \
+        MNX_X3_ST1(v[0], o_, 0); MNX_X3_ST1(v[1], o_, 64); MNX_X3_ST1(v[2], o_, 128); MNX_X3_ST1(v[3], o_, 192);         \
+    } while (0)
+#else
+            // row-major mapping: lane l <-> row (l >> 3) (+ 8 for the second access), 16 bytes at column 4 (l & 7) of a
+            // 32-column half: d[2 h + i] = rows 8 i .. 8 i + 7 of half h
+            const unsigned voff = (unsigned)((((lane >> 3)) * N + (lane & 7) * 4) * 4);
+            const unsigned half_b = (unsigned)N * 32u;                // 8 rows
+#define MNX_X3_LD(d, mt)                                                                                                  \
+    do {                                                                                                                  \
+        const unsigned o_ = voff + (unsigned)(mt) * slab_b, o8_ = o_ + half_b;                                            \
+        MNX_X3_LD1(d[0], o_, 0); MNX_X3_LD1(d[1], o8_, 0); MNX_X3_LD1(d[2], o_, 128); MNX_X3_LD1(d[3], o8_, 128);        \
+    } while (0)
+#define MNX_X3_ST(v, mt)                                                                                                  \
+    do {                                                                                                                  \
+        const unsigned o_ = voff + (unsigned)(mt) * slab_b, o8_ = o_ + half_b;                                            \
+        MNX_X3_ST1(v[0], o_, 0); MNX_X3_ST1(v[1], o8_, 0); MNX_X3_ST1(v[2], o_, 128); MNX_X3_ST1(v[3], o8_, 128);        \
+    } while (0)
+#endif
+            f32x4 r[4][4];
+            if (RES && !LAB_NOGLB) {
+                MNX_X3_LD(r[0], 0); MNX_X3_LD(r[1], 1); MNX_X3_LD(r[2], 2); MNX_X3_LD(r[3], 3);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                f32x4 v[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    v[nt] = acc[mt][nt] * sp.oscale + b4[nt];
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#if MNX_X3_EPI32 == 2
+                // accumulator mapping -> row-major mapping through the wave's staging patch, one 32-column half at a time
+                // (16 rows x 128 B = the 2 KiB patch; a wave's LDS operations execute in order)
+                f32x4 t[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) *(f32x4*)(stg + fr * 128 + (((q * 4 + fg) ^ (fr & 7)) << 4)) = v[2 * h + q];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = (lane >> 3) + 8 * i;
+                        t[2 * h + i] = *(const f32x4*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = t[q];
+#endif
+                if (RES && !LAB_NOGLB) {
+                    x3_wait_younger(mt);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm volatile("" : "+v"(r[mt & 3][q]));           // from here on the compiler may read the loaded registers
+                        v[q] += r[mt & 3][q];
+                    }
+                }
+                if (LAB_NOGLB) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(v[q]));
+                } else {
+                    MNX_X3_ST(v, mt);
+                    if (RES && mt + 4 < 8) MNX_X3_LD(r[mt & 3], mt + 4);
+                }
+            }
+#undef MNX_X3_LD
+#undef MNX_X3_ST
+#undef MNX_X3_LD1
+#undef MNX_X3_ST1
+            return;
+#endif
         }
         // ---- 16-bit output: 16-row slabs through the wave's own staging patch, hi plane then lo plane ----
         T* crow = C + (size_t)(m0 + wr * 128 + (lane >> 3)) * N + n0 + wc * 64 + (lane & 7) * 8;
@@ -506,7 +689,7 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 f32x4 v = acc[mt][nt] * sp.oscale + b4[nt];
-                if (EPI == EPI_GELU_16) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                if (EPI == EPI_GELU_16) v = gelu_split4(v);
                 v4 hi;
                 split16x4<T>(v, hi, lo[nt]);
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -516,7 +699,8 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
             for (int i = 0; i < 2; ++i) {
                 const int row = (lane >> 3) + 8 * i;
                 const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-                *(v8*)(crow + (size_t)(mt * 16 + 8 * i) * N) = o8;
+                if (LAB_NOGLB) asm volatile("" ::"v"(o8));
+                else *(v8*)(crow + (size_t)(mt * 16 + 8 * i) * N) = o8;
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -525,7 +709,8 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
             for (int i = 0; i < 2; ++i) {
                 const int row = (lane >> 3) + 8 * i;
                 const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-                *(v8*)(crow + sp.c_lo + (size_t)(mt * 16 + 8 * i) * N) = o8;
+                if (LAB_NOGLB) asm volatile("" ::"v"(o8));
+                else *(v8*)(crow + sp.c_lo + (size_t)(mt * 16 + 8 * i) * N) = o8;
             }
         }
     };
@@ -548,52 +733,59 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
         const bool first_kt = (kt == 0 && seq > 0);
         const bool drain = (g == 0) || !has_next;
         // ---- P1: Ah0 . Wl -> rows 0..63.   refill: A lo rows 64-127 of THIS K-tile (its slot was read last in P6)
-        fill_a(cur.a + a_lo_b, 1, S_AL1);
+        const bool rd = !LAB_NOREAD || g == 0;
+        if (!LAB_NOFILL || g == 0) fill_a(cur.a + a_lo_b, 1, S_AL1);
         if (first_kt) load_bias(n0);
-        read_a(R_AH0{});
-        read_w(R_WL{});
+        if (rd) { read_a(R_AH0{}); read_w(R_WL{}); }
         // Ah1 (issued in P3 of the previous K-tile). Younger: P4 4, P5 2, P6 2 [, PST stores], this phase's 2 [+ bias]
         MNX_X3_WAIT(10, PST + X3_BIAS);
         mfma_block(MB0{});
         __builtin_amdgcn_s_barrier();
         // ---- P2: Ah1 . Wl -> rows 64..127.   refill: W lo of the next K-tile
-        if (has_next) fill_w(nxt.w + w_lo_b, S_WL0);
-        read_a(R_AH1{});
+        if (has_next && !LAB_NOFILL) fill_w(nxt.w + w_lo_b, S_WL0);
+        if (rd) read_a(R_AH1{});
         // W hi (issued in P4 of the previous K-tile). Younger: P5 2, P6 2 [, PST stores], P1 2 [+ bias], P2 4
         MNX_X3_WAIT(10, PST + X3_BIAS);
         mfma_block(MB4{});
         __builtin_amdgcn_s_barrier();
         // ---- P3: Ah1 . Wh -> rows 64..127.   refill: A hi rows 64-127 of the next K-tile.   P4 re-reads Ah0: landed before P1
-        if (has_next) fill_a(nxt.a, 1, S_AH1);
-        read_w(R_WH{});
+        if (has_next && !LAB_NOFILL) fill_a(nxt.a, 1, S_AH1);
+        if (rd) read_w(R_WH{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         mfma_block(MB4{});
         __builtin_amdgcn_s_barrier();
         // ---- P4: Ah0 . Wh -> rows 0..63.   refill: W hi of the next K-tile (its fragments stay in registers until P6)
-        if (has_next) fill_w(nxt.w, S_WH0);
-        read_a(R_AH0{});
+        if (has_next && !LAB_NOFILL) fill_w(nxt.w, S_WH0);
+        if (rd) read_a(R_AH0{});
         // Al0 (issued in P6 of the previous K-tile, before its epilogue). Younger: [PST stores,] P1 2 [+ bias], P2 4, P3 2, P4 4
         MNX_X3_WAIT(12, PST + X3_BIAS);
         mfma_block(MB0{});
         __builtin_amdgcn_s_barrier();
         // ---- P5: Al0 . Wh -> rows 0..63.   refill: A hi rows 0-63 of the next K-tile
-        if (has_next) fill_a(nxt.a, 0, S_AH0);
-        read_a(R_AL0{});
+        if (has_next && !LAB_NOFILL) fill_a(nxt.a, 0, S_AH0);
+        if (rd) read_a(R_AL0{});
         // Al1 (issued in P1 of this K-tile, before the bias DMA). Younger: [bias,] P2 4, P3 2, P4 4, P5 2
         MNX_X3_WAIT(12, X3_BIAS);
         mfma_block(MB0{});
         __builtin_amdgcn_s_barrier();
         // ---- P6: Al1 . Wh -> rows 64..127.   refill: A lo rows 0-63 of the next K-tile
-        if (has_next) fill_a(nxt.a + a_lo_b, 0, S_AL0);
-        read_a(R_AL1{});
+        if (has_next && !LAB_NOFILL) fill_a(nxt.a + a_lo_b, 0, S_AL0);
+        if (rd) read_a(R_AL1{});
         // Ah0', Wl' of the next K-tile (issued in P5 / P2). Younger than Ah0': this phase's 2
         MNX_X3_WAIT(2, 0);
         mfma_block(MB4{});
         // epilogue placement as gemm256_kernel: second wave row before its closing barrier, first row after its own
+#if MNX_X3_LAB & 16
+        unsigned long long lab_e0 = 0;
+        if (last_kt) lab_e0 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (last_kt && wr == 1) epilogue();
         __builtin_amdgcn_s_barrier();
         if (last_kt && wr == 0) epilogue();
+#if MNX_X3_LAB & 16
+        if (last_kt) lab_epi += __builtin_amdgcn_s_memrealtime() - lab_e0;     // tile end -> this wave is through its epilogue code
+#endif
         cur = nxt;
         advance(nxt);
         if (last_kt) {
@@ -605,6 +797,15 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     }
 #undef MNX_X3_WAIT
     if (wr == 0) __builtin_amdgcn_s_barrier();    // the first wave row waits for the second one's last segment
+#if MNX_X3_LAB & 16
+    if (lane == 0 && (wave == 0 || wave == 4)) {
+        unsigned long long* o = x3_lab_stamps + blockIdx.x * 8 + (wave >> 2) * 4;
+        o[0] = __builtin_readcyclecounter() - lab_c0;
+        o[1] = __builtin_amdgcn_s_memrealtime() - lab_r0;
+        o[2] = lab_epi;
+        o[3] = (unsigned long long)my_tiles;
+    }
+#endif
 }
 
 }  // namespace
@@ -625,6 +826,12 @@ static hipError_t lds_opt_in(int lds_bytes = P_LDS) {
     return e;
 }
 
+// Workgroups of a persistent launch (one per CU). 256 = the whole chip; the engine lowers it when the decode stream owns a
+// CU partition (engine.hip, MNX_DEC_CUS), tools/gemm_lab to see how the loop scales with the CUs it runs on.
+static int g_persistent_cus = 256;
+void set_persistent_cus(int n) { g_persistent_cus = n < 1 ? 1 : n > 256 ? 256 : n; }
+int persistent_cus() { return g_persistent_cus; }
+
 // gemm256x3_kernel: split dtypes, any of the four epilogues, whole 256x256 tiles, >= 2 K-tiles.
 bool gemm256x3_supports(int dtype, int epi, int M, int N, int K) {
     if (!dt_split(dtype)) return false;
@@ -639,10 +846,8 @@ hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, vo
     if (!bias) return hipErrorInvalidValue;     // callers without a bias pass a zero vector (the engine keeps one)
     const SplitArgs spv = *sp;
     const int tm = M / TM, tn = N / TN;
-#ifndef MNX_X3_GRID             // tools/gemm_lab builds variants with fewer workgroups (what bounds the epilogue: the CU or the chip?)
-#define MNX_X3_GRID 256
-#endif
-    const int grid = tm * tn < MNX_X3_GRID ? tm * tn : MNX_X3_GRID;
+    const int cus = persistent_cus();
+    const int grid = tm * tn < cus ? tm * tn : cus;
 #define MNX_G256X3_CASE(TT, E)                                                                                            \
     case E: {                                                                                                             \
         const hipError_t attr = lds_opt_in<gemm256x3_kernel<TT, E>>(X3_LDS);                                                 \
@@ -662,6 +867,12 @@ hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, vo
 #undef MNX_G256X3_CASE
     return hipGetLastError();
 }
+
+#if MNX_X3_LAB & 16
+hipError_t x3_lab_read_stamps(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(x3_lab_stamps), sizeof(unsigned long long) * 256 * 8);
+}
+#endif
 
 bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
     if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16 && !dt_split(dtype)) return false;

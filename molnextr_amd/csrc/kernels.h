@@ -48,6 +48,9 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
 // tile it is given on one workgroup per CU in rounds of 256: launch_gemm16 hands it whole rounds and the 128x128 kernel
 // the remaining rows.
 bool gemm256x3_supports(int dtype, int epi, int M, int N, int K);
+// workgroups of a persistent launch = CUs the encoder stream may occupy (default 256, the whole chip)
+void set_persistent_cus(int n);
+int persistent_cus();
 hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                             const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp);
 

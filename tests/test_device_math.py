@@ -94,12 +94,50 @@ def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
             assert waits == [0, 0, 0, 0, 0, 2, 2, 8, 10, 10, 12, 12, 13, 43, 43, 45], (name, waits)
             assert len(re.findall(r"s_barrier", body)) == 15, name
         else:
-            # fp32 epilogues use ordinary loads / stores: the compiler adds its own (stricter) waits inside the epilogue and
-            # may duplicate the K-tile body; the counted waits of the phases must all be there
-            expect = {10: 2, 12: 2, 13: 1, 8: 1}
-            expect.update({63: 3} if "Li2E" in name else {43: 2, 45: 1})
+            # fp32 epilogues (form 2, gemm256.hip MNX_X3_EPI32): residual loads and stores are inline asm on ONE scalar base
+            # per array + a 32-bit lane offset, retired by counted waits — four slabs of residual in flight, 12 16 20 24 24 20
+            # 16 12 younger operations allowed when slab 0..7 is consumed. The compiler sees no vector-memory operation in
+            # the epilogue, so it adds no wait of its own (it may duplicate the K-tile body and the two copies of the epilogue)
+            resid = "Li2E" in name
+            expect = {10: 2, 13: 1, 8: 1}
+            expect.update({63: 3} if resid else {43: 2, 45: 1})
             for w, n in expect.items():
                 assert waits.count(w) >= n and waits.count(w) % n == 0, (name, w, waits.count(w))
+            copies = waits.count(24) // 2 if resid else 0
+            if resid:
+                assert copies >= 2 and waits.count(16) == 2 * copies and waits.count(20) == 2 * copies, (name, waits)
+                assert waits.count(12) >= 2 * copies + 2, (name, waits)          # + the two phase waits of 12
+            assert not any(w in waits for w in (1, 3, 4, 5, 6, 7)), (name, waits)     # what a compiler-made wait would look like
+            ld = re.findall(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\]", body)
+            st = re.findall(r"global_store_dwordx4 v\d+, v\[\d+:\d+\], s\[\d+:\d+\]", body)
+            n_ld = len(re.findall(r"global_load_dwordx4", body)), len(re.findall(r"global_store_dwordx4", body))
+            assert (len(ld), len(st)) == n_ld and len(st) % 32 == 0 and len(st) >= 64, (name, n_ld)
+            assert len(ld) == (len(st) if resid else 0), (name, len(ld), len(st))
+            # the hazard the compiler cannot see through asm: a VALU / LDS-read / load result written into the DATA registers of
+            # a 16-byte store within two wait states of it (gfx940+). The first build had one wait state: one wrong word in 512
+            lines = [l.strip() for l in body.split("\n")]
+            lines = [l for l in lines if l and not l.startswith(";") and not l.startswith(".")]
+            def regs(tok):
+                m = re.match(r"v\[(\d+):(\d+)\]", tok)
+                if m:
+                    return set(range(int(m.group(1)), int(m.group(2)) + 1))
+                m = re.match(r"v(\d+)$", tok)
+                return {int(m.group(1))} if m else set()
+            for i, l in enumerate(lines):
+                if not l.startswith("global_store_dwordx4"):
+                    continue
+                data = regs(l.split()[2].strip(","))
+                assert len(data) == 4, l
+                ws, k = 0, i + 1
+                while ws < 2 and k < len(lines):
+                    nxt = lines[k]
+                    if nxt.startswith("s_nop"):
+                        ws += int(nxt.split()[1]) + 1
+                    else:
+                        if nxt.startswith(("v_", "ds_read", "global_load_dwordx4")):
+                            assert not (regs(nxt.split()[1].strip(",")) & data), (name, l, nxt)
+                        ws += 1
+                    k += 1
 
 
 def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fetch_queue(tmp_path):

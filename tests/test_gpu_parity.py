@@ -310,11 +310,13 @@ def test_beam1_equals_greedy(eng, dev):
         assert abs(b["scores"][i, 0].item() - lp) < 1e-3 * max(1.0, abs(lp))
 
 
-def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, branch_rows=0, branch_max=4, xcd=0):
+def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, branch_rows=0, branch_max=4, xcd=0, mid_max=0):
     """An engine whose greedy tick runs fused on the given row tiles (tile 0: the 8-launches-per-layer tick of decoder.hip),
-    ticks of more than branch_rows rows as up to branch_max parallel branches of rows (0: one chain)."""
+    ticks of more than branch_rows rows as up to branch_max parallel branches of rows (0: one chain); ticks of more than
+    fused_max and up to mid_max rows take the mid form (dec_ma + dec_mb in place of dec_fa)."""
     from molnextr_amd.engine import Engine
     keys = {"MNX_DEC_TILE": str(tile), "MNX_DEC_TILE_FF": str(tile_ff), "MNX_DEC_FUSED_MAX": str(fused_max),
+            "MNX_DEC_MID_MAX": str(mid_max),
             "MNX_DEC_BRANCH_ROWS": str(branch_rows), "MNX_DEC_BRANCH_MAX": str(branch_max), "MNX_DEC_XCD": str(xcd)}
     old = {k: os.environ.get(k) for k in keys}
     os.environ.update(keys)
@@ -335,15 +337,19 @@ def test_fused_tick_is_independent_of_the_row_tiles_and_matches_the_unfused_tick
     finish at different steps (compaction, PE quirk) and run up to position 479 (second key per thread, value loop tail)."""
     feats = eng.encode(W.synthetic_images(32).to(dev))
     outs = {}
-    for tiles in ((4, 4), (2, 8), (4, 16), (0, 4), (2, 4, "xcd"), (4, 8, "xcd")):
-        e = _engine_with_tick(synth_ckpt, tiles[0], tiles[1], xcd=int(len(tiles) > 2))
+    for tiles in ((4, 4), (2, 8), (4, 16), (0, 4), (2, 4, "xcd"), (4, 8, "xcd"), (4, 4, "mid")):
+        mid = len(tiles) > 2 and tiles[2] == "mid"      # the 32-row tick on the mid form: fused only up to 16 rows
+        e = _engine_with_tick(synth_ckpt, tiles[0], tiles[1], xcd=int(len(tiles) > 2 and not mid), fused_max=16 if mid else 128,
+                              mid_max=4096 if mid else 0)
         try:
             a = e.decode_greedy(feats)
             b = e.decode_greedy(feats[:5].contiguous(), max_len=480, stop_on_eos=False)
             outs[tiles] = tuple({k: v.cpu() for k, v in o.items() if v is not None} for o in (a, b))
         finally:
             e.close()
-    for tiles in ((2, 8), (4, 16), (2, 4, "xcd"), (4, 8, "xcd")):      # "xcd": row tiles pinned to XCDs (another grid order)
+    # "xcd": row tiles pinned to XCDs (another grid order); "mid": dec_fa cut into its linear half on 16-row tiles and its
+    # attention half (dec_ma / dec_mb), every key of the row read from the cache — the same chains on the same numbers
+    for tiles in ((2, 8), (4, 16), (2, 4, "xcd"), (4, 8, "xcd"), (4, 4, "mid")):
         for x, y in zip(outs[(4, 4)], outs[tiles]):
             assert torch.equal(x["lengths"], y["lengths"]), f"tiles {tiles}"
             for i, n in enumerate(x["lengths"].tolist()):
@@ -365,9 +371,11 @@ def test_fused_and_unfused_ticks_mix_in_one_job(eng, dev, synth_ckpt):
     res = []
     # (tile, fused_max, branch_rows, branch_max): the last three vary how a tick is cut into parallel branches of rows —
     # one chain, two branches of 96 rows (fused), five of 32, two of 96 on the 8-launch form — which must not change anything
-    for tile, fmax, brows, bmax, xcd in ((4, 64, 128, 4, 0), (4, 4096, 0, 1, 0), (0, 0, 0, 1, 0), (2, 128, 128, 4, 0), (4, 128, 32, 8, 0),
-                                         (0, 0, 96, 2, 0), (-1, 4096, 0, 1, 1)):
-        e = _engine_with_tick(synth_ckpt, tile, 4, fmax, slots=256, branch_rows=brows, branch_max=bmax, xcd=xcd)
+    # the last two: the job starts on the MID form (capacity 192 > 64 / 128) and drains on the fused one; mid form throughout
+    for tile, fmax, brows, bmax, xcd, mmax in ((4, 64, 128, 4, 0, 0), (4, 4096, 0, 1, 0, 0), (0, 0, 0, 1, 0, 0), (2, 128, 128, 4, 0, 0),
+                                               (4, 128, 32, 8, 0, 0), (0, 0, 96, 2, 0, 0), (-1, 4096, 0, 1, 1, 0),
+                                               (-1, 64, 0, 1, 0, 4096), (-1, 128, 0, 1, 0, 4096), (4, 16, 0, 1, 0, 4096)):
+        e = _engine_with_tick(synth_ckpt, tile, 4, fmax, slots=256, branch_rows=brows, branch_max=bmax, xcd=xcd, mid_max=mmax)
         try:
             res.append({k: v.cpu() for k, v in e.predict(imgs, ref_batch=32).items()})
         finally:

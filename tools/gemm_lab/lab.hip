@@ -17,10 +17,23 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
 #include "kernels.h"
+
+#ifdef MNX_X3_LAB
+#define MNX_X3_LAB_V MNX_X3_LAB
+#else
+#define MNX_X3_LAB_V 0
+#define MNX_X3_LAB 0
+#endif
+#ifdef MNX_X3_EPI32
+#define MNX_X3_EPI32_V MNX_X3_EPI32
+#else
+#define MNX_X3_EPI32_V -1
+#endif
 
 #define CK(x)                                                                                     \
     do {                                                                                          \
@@ -70,6 +83,18 @@ __global__ void ref_rows(const bf16_t* A, const bf16_t* W, const float* bias, co
     out[(size_t)s * N + n] = acc;
 }
 
+// split modes: the dispatched kernels must reproduce the 128x128 kernel bit for bit (they add the same fp32 numbers in the same
+// order: DESIGN.md 4.3) — every 4-byte word of both outputs is compared
+__global__ void cmp_words(const unsigned* a, const unsigned* b, size_t n, unsigned long long* out) {
+    unsigned long long bad = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) bad += a[i] != b[i];
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, bad);
+}
+#if MNX_X3_LAB & 16
+namespace mnx { hipError_t x3_lab_read_stamps(unsigned long long* host); }
+#endif
+
 struct Shape { const char* name; int epi, M, N, K; };
 
 int main(int argc, char** argv) {
@@ -100,6 +125,13 @@ int main(int argc, char** argv) {
         printf("background copy alone: %.2f TB/s (read + write), %d workgroups\n", 10 * 2.0 * bn * 16 / (ms * 1e-3) * 1e-12, bg_wgs);
     }
     const int dt = split ? mnx::MNX_DT_F16X3 : mnx::MNX_DT_BF16;
+    // environment: MNX_LAB_ZERO=1 all operands zero (what does the clock do without toggling data?), MNX_LAB_CUS=n persistent
+    // launches on n workgroups, MNX_LAB_NOBASE=1 the 128x128 kernel is run once (for the comparison) but not timed
+    const bool zero = getenv("MNX_LAB_ZERO") && atoi(getenv("MNX_LAB_ZERO"));
+    const bool nobase = getenv("MNX_LAB_NOBASE") && atoi(getenv("MNX_LAB_NOBASE"));
+    if (getenv("MNX_LAB_CUS")) mnx::set_persistent_cus(atoi(getenv("MNX_LAB_CUS")));
+    printf("lab build: MNX_X3_LAB=%d MNX_X3_EPI32=%d, persistent workgroups %d%s\n", MNX_X3_LAB_V, MNX_X3_EPI32_V, mnx::persistent_cus(),
+           zero ? ", ZERO operands" : "");
     std::vector<Shape> shapes;
     const int L[4] = {9216, 2304, 576, 144}, C[4] = {128, 256, 512, 1024};
     static char names[64][32];
@@ -140,6 +172,7 @@ int main(int argc, char** argv) {
             fill_bf16<<<2048, 256, 0, st>>>(A, nA, 1u, 1.0f);
             fill_bf16<<<2048, 256, 0, st>>>(W, nW, 2u, 1.0f / sqrtf((float)sh.K));
         }
+        if (zero) { CK(hipMemsetAsync(A, 0, nA * 2 * planes, st)); CK(hipMemsetAsync(W, 0, nW * 2 * planes, st)); }
         fill_f32<<<64, 256, 0, st>>>(bias, sh.N, 3u, 0.5f);
         if (sh.epi == 2) fill_f32<<<2048, 256, 0, st>>>(resid0, nC, 4u, 1.0f);
         const int S = 24;
@@ -161,9 +194,21 @@ int main(int argc, char** argv) {
                      : mnx::launch_gemm16_tile128(dt, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st, split ? &sp : nullptr);
         };
         double us[2] = {0, 0}, err[2] = {0, 0};
+        const size_t cbytes = nC * (out16 ? 2 * planes : 4);
+        void* Cb = nullptr;                       // split modes: the 128x128 kernel's output, for the word-by-word comparison
+        unsigned long long* dbad = nullptr;
+        unsigned long long bad = 0;
+        if (split) { CK(hipMalloc(&Cb, cbytes)); CK(hipMalloc(&dbad, 8)); CK(hipMemsetAsync(dbad, 0, 8, st)); }
         for (int v = 0; v < 2; ++v) {
             if (sh.epi == 2) CK(hipMemcpyAsync(Cc, resid0, nC * 4, hipMemcpyDeviceToDevice, st));
             CK(launch(v));
+            if (split && v == 0) CK(hipMemcpyAsync(Cb, Cc, cbytes, hipMemcpyDeviceToDevice, st));
+            if (split && v == 1) {
+                cmp_words<<<2048, 256, 0, st>>>((const unsigned*)Cb, (const unsigned*)Cc, cbytes / 4, dbad);
+                CK(hipMemcpyAsync(&bad, dbad, 8, hipMemcpyDeviceToHost, st));
+                CK(hipStreamSynchronize(st));
+            }
+            if (nobase && v == 0) continue;
             std::vector<char> hrow((size_t)sh.N * 4);
             for (int i = 0; i < S && !split; ++i) {
                 CK(hipMemcpyAsync(hrow.data(), (char*)Cc + (size_t)rows[i] * sh.N * (out16 ? 2 : 4), (size_t)sh.N * (out16 ? 2 : 4),
@@ -203,10 +248,35 @@ int main(int argc, char** argv) {
         }
         const double fl = 2.0 * sh.M * sh.N * sh.K;
         const double tol = out16 ? 2e-2 : 1e-3;
-        printf("%-9s %3d %8d %6d %6d | %10.1f %8.1f | %10.1f %8.1f %-6s| %.2e %.2e%s\n", sh.name, sh.epi, sh.M, sh.N, sh.K, us[0],
-               fl / us[0] / 1e6, us[1], fl / us[1] / 1e6,
+        printf("%-9s %3d %8d %6d %6d | %10.1f %8.1f | %10.1f %8.1f %-6s| %.2e %.2e%s", sh.name, sh.epi, sh.M, sh.N, sh.K, us[0],
+               us[0] > 0 ? fl / us[0] / 1e6 : 0.0, us[1], fl / us[1] / 1e6,
                mnx::gemm16_route(dt, sh.epi, sh.M, sh.N, sh.K, 3, true), err[0], err[1],
                (err[0] > tol || err[1] > tol) ? "  FAIL" : "");
+        if (split) printf(" | words differing from the 128x128 kernel: %llu of %zu%s", bad, cbytes / 4, bad ? (MNX_X3_LAB_V & 47 ? " (ablation)" : "  MISMATCH") : "");
+        printf("\n");
+#if MNX_X3_LAB & 16
+        {   // clock stamps of the LAST launch: per workgroup {shader cycles, 100 MHz ticks, ticks inside epilogue code, tiles} x 2 wave rows
+            std::vector<unsigned long long> hs(256 * 8);
+            CK(mnx::x3_lab_read_stamps(hs.data()));
+            const int g = mnx::persistent_cus();
+            std::vector<double> mhz, dur, epi;
+            for (int w = 0; w < g; ++w) {
+                const unsigned long long* o = hs.data() + w * 8;
+                if (!o[1]) continue;
+                mhz.push_back((double)o[0] / (double)o[1] * 100.0);
+                dur.push_back(o[1] * 0.01);
+                epi.push_back(o[3] ? o[2] * 0.01 / o[3] : 0.0);
+            }
+            if (!mhz.empty()) {
+                std::sort(mhz.begin(), mhz.end()); std::sort(dur.begin(), dur.end()); std::sort(epi.begin(), epi.end());
+                const size_t n = mhz.size();
+                printf("   stamps (%zu workgroups): shader clock MHz min / median / max %.0f / %.0f / %.0f; workgroup lifetime us %.1f / %.1f / %.1f;"
+                       " tile end -> epilogue code done, us per tile %.2f / %.2f / %.2f\n", n, mhz[0], mhz[n / 2], mhz[n - 1], dur[0], dur[n / 2],
+                       dur[n - 1], epi[0], epi[n / 2], epi[n - 1]);
+            }
+        }
+#endif
+        if (split) { CK(hipFree(Cb)); CK(hipFree(dbad)); }
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(Cc)); CK(hipFree(resid0)); CK(hipFree(drows)); CK(hipFree(ref));
     }
     return 0;
