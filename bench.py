@@ -203,17 +203,39 @@ def cpu_baseline(ck, budget_s=85.0):
             "host": host, "thread_sweep": sweep, "runs": rows}
 
 
-def sustained_rate_reference():
-    """The sustained 16-bit MFMA rate measured once with tools/probes/mfma_rate.hip (profiles/r03_mfma_sustained_rate.json says
-    where and when); a reference figure, `roofline.peak` stays the guide's nominal 2.5 PFLOP/s."""
-    path = os.path.join(ROOT, "profiles", "r03_mfma_sustained_rate.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        d["source"] = "profiles/r03_mfma_sustained_rate.json (a committed measurement of round 3, not of this run)"
-        return d
-    except OSError:
-        return None
+def library_sha16():
+    """First 16 hex digits of the sha256 over the kernel sources (molnextr_amd/csrc/*.hip, *.h, the public header) the loaded
+    library is built from: a measurement file made with other kernels is not evidence about these. (The sources rather than
+    the .so: two builds of the same sources need not be byte-identical. tools/collect_traffic.py computes the same digest.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "molnextr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "molnextr_amd", "csrc", "*.h"))
+                   + [os.path.join(ROOT, "include", "molnextr_hip.h")])
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def gemm_traffic(dtype, eb):
+    """HBM bytes per encoder GEMM launch from the rocprofv3 --pmc passes of tools/gpu/profiles.sh (tools/collect_traffic.py writes
+    profiles/r05_gemm_traffic_<dtype>_b<images>.json and stamps it with the digest of the kernel sources it profiled). The
+    counters cannot be collected inside a timed run, so the figure comes from a file — but only from one made with THESE
+    kernels: (bytes, source) or (None, why not)."""
+    name = f"r05_gemm_traffic_{dtype}_b{eb}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"profiles/{name} not present (tools/gpu/profiles.sh makes it)"
+    with open(path) as f:
+        d = json.load(f)
+    have = library_sha16()
+    if d.get("library_sha16") != have:
+        return None, (f"profiles/{name} was made with kernel sources {d.get('library_sha16')}, this run's are {have}: refused "
+                      "(re-run tools/gpu/profiles.sh with this build)")
+    return round(d["hbm_bytes_per_launch"]), (f"profiles/{name}: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the same "
+                                              f"encoder launches, kernel sources {have}")
 
 
 def plan_launch(gpus, env, device_count):
@@ -431,7 +453,9 @@ def main():
     torch.cuda.synchronize()
     if live:
         eng.profile(stride)              # HIP events on the encoder stream, live inside the timed region
+    eng.gemm_clock(reset=True)           # shader-clock counters of the persistent GEMM launches: zeroed before the timed region
     elapsed = timed(lambda: process(eng, imgs, args.steps, mode))
+    gemm_mhz = eng.gemm_clock(reset=True)     # ... and read after it: every gemm256x3 launch of the timed job
     live_prof = eng.profile_read_all() if live else None
     eng.profile(False)
     main_stats = dict(stats)
@@ -469,17 +493,10 @@ def main():
         si_ms, si_flop, si_n = family(iso, ("gemm_s34",))
         s34 = s_flop / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
         s34_iso = si_flop / (si_ms * 1e-3) / 1e12 if si_ms > 0 else 0.0
-        traffic, traffic_src = None, None
-        for name in (f"r04_gemm_traffic_{args.dtype}_b{eb}.json", f"r03_gemm_traffic_{args.dtype}_b{eb}.json",
-                     f"r02_gemm_traffic_b{eb}.json"):
-            if name.startswith("r02") and args.dtype != "bf16":
-                continue
-            tpath = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tpath):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_traffic.py)
-                with open(tpath) as f:
-                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
-                traffic_src = f"profiles/{name} (separate rocprofv3 --pmc passes over the same encoder launches)"
-                break
+        traffic, traffic_src = gemm_traffic(args.dtype, eb)
+        # what the matrix pipes sustain on THIS device under its power budget (register-only fp16 MFMA loop on random
+        # operands, ~30 ms, measured now): the encoder GEMMs are power-limited, the nominal 2.5 PFLOP/s assumes 2.4 GHz
+        sus_tf, sus_mhz = eng.probe_mfma(30)
         mfma = {"fp16x3": "v_mfma_f32_16x16x32_f16 x 3 terms", "bf16x3": "v_mfma_f32_16x16x32_bf16 x 3 terms",
                 "bf16": "v_mfma_f32_16x16x32_bf16", "fp16": "v_mfma_f32_16x16x32_f16", "fp32": "v_mfma_f32_16x16x4_f32"}[args.dtype]
         roofline = {"kernel": f"mnx::gemm_tn_* + mnx::gemm256*_kernel ({mfma}, all encoder Linear layers)",
@@ -487,6 +504,15 @@ def main():
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "work": "algorithmic FLOP = 2*M*N*K per launch",
                     "mfma_terms": terms, "frac_of_peak_executed": round(terms * achieved / PEAK_BF16_TFLOPS, 4),
+                    # the chip clocks to its power budget: the persistent GEMM kernel's own stamps (shader cycles / wall ticks,
+                    # every launch of the timed job) and what a register-only MFMA loop on random operands sustains right now
+                    "clock": {"gemm_shader_mhz_live": round(gemm_mhz, 0), "nominal_mhz": 2400,
+                              "peak_at_live_clock": round(PEAK_BF16_TFLOPS * gemm_mhz / 2400.0, 1) if gemm_mhz > 0 else None,
+                              "frac_of_peak_at_live_clock_executed": (round(terms * achieved / (PEAK_BF16_TFLOPS * gemm_mhz / 2400.0), 4)
+                                                                      if gemm_mhz > 0 else None),
+                              "sustained_mfma_tflops": round(sus_tf, 1), "sustained_mfma_mhz": round(sus_mhz, 0),
+                              "frac_of_sustained_executed": round(terms * achieved / sus_tf, 4) if sus_tf > 0 else None,
+                              "what": "mnx_gemm_clock / mnx_probe_mfma, both measured in this run (include/molnextr_hip.h)"},
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb, 2 if split else 1)),
                     "images_per_launch": eb,
@@ -584,8 +610,7 @@ def main():
             "rccl_ranks": rccl_ranks,
             "host_cpus_per_rank": len(rank_cpu_set) if rank_cpu_set else None,
             "roofline": roofline, "roofline_extra": extra, "sub_results": sub, "cpu_baseline": cpu,
-            # NOT measured in this run (kept out of `roofline` for that reason): what the matrix pipes sustain on this chip
-            "references": {"mfma_sustained_rate": sustained_rate_reference()},
+            "library_sha16": library_sha16(),
             "parity_note": ("SMILES exact-match vs the reference is checked on the raw token SMILES + atom / bond sets (RDKit is not "
                             "installable here). dtype fp16x3 (this line's default) and fp32: logits within 1e-3, every token / atom / "
                             "bond equal to the reference from pixels (tests/test_gpu_pixels.py, 32 + 6 images, free-running and "

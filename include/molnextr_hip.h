@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNX_ABI_VERSION 5
+#define MNX_ABI_VERSION 6
 
 typedef struct mnx_engine mnx_engine;
 
@@ -277,6 +277,18 @@ int mnx_profile_read(mnx_engine* h, int32_t kind, double* ms, double* work, int6
  * (cross K+V). Overwrites the decoder state: not to be called while a decode call is in flight. */
 int mnx_probe_decode_attn(mnx_engine* h, int32_t rows, int32_t t, int32_t iters, double* self_ms, double* cross_ms,
                           void* stream);
+
+/* Measurement aids (ABI 6): the encoder GEMMs are POWER-limited on this chip — the shader clock under the split-operand GEMM
+ * kernel is 1.65-1.9 GHz with real operands against 2.4 GHz nominal — so a rate is reported next to the clock it
+ * was reached at and next to what the matrix pipes sustain on this device.
+ * mnx_gemm_clock: shader clock (MHz; shader cycles / 100 MHz wall ticks of one workgroup per launch) averaged over the persistent
+ *   GEMM launches (mnx::gemm256x3_kernel) since the last reset; 0.0 when none ran. Synchronises the device. The counters are
+ *   per process (all engines of the device share them).
+ * mnx_probe_mfma: runs a register-only loop of v_mfma_f32_16x16x32_f16 on random operands on every CU for about ms_target
+ *   milliseconds (after a shorter settling launch) and returns its rate (TFLOP/s) and shader clock: the ceiling of any fp16
+ *   MFMA kernel under this device's power budget — no reference-side counterpart (measurement only). */
+int mnx_gemm_clock(mnx_engine* h, int32_t reset, double* mhz);
+int mnx_probe_mfma(mnx_engine* h, int32_t ms_target, double* tflops, double* mhz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,7 +104,7 @@ struct mnx_engine {
     // host happens to pick — it follows poll timing — is invisible in the results up to dec_mid_max rows); beyond that the
     // 8-launches-per-layer kernels of decoder.hip, whose 32-row linears move the fewest bytes per row (MNX_DEC_MID_MAX;
     // 4096 = every capacity: bit-reproducible jobs of any size, slower at >= 1024 rows)
-    int dec_mid_max = 640;
+    int dec_mid_max = 0;
     int dec_xcd = 0;           // fused tick: row tiles pinned to XCDs so that a row's partial planes stay in one L2 (MNX_DEC_XCD)
     // a tick of more than dec_branch_rows rows can be enqueued as up to dec_branch_max BRANCHES of rows on parallel branches
     // of the tick graph (rows are independent through the whole stack). OFF by default (0): measured, the branches of a
@@ -1318,6 +1318,23 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
     HIPCHK(h, hipStreamSynchronize(s));
     if (tf) fprintf(tf, "%.3f end host_wait_ms %.3f\n", now_ms() - t_begin, host_wait_ms);
     return check_encoder_range(h, s);
+}
+
+int mnx_gemm_clock(mnx_engine* h, int32_t reset, double* mhz) {
+    if (!h || !mhz) return MNX_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, x3_clock_read(mhz, reset != 0));
+    return MNX_OK;
+}
+
+int mnx_probe_mfma(mnx_engine* h, int32_t ms_target, double* tflops, double* mhz, void* stream) {
+    if (!h || !tflops || !mhz || ms_target < 1 || ms_target > 2000) return MNX_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    // 8 MFMAs of 16 cycles per iteration and wave, two waves per SIMD: ~256 cycles per iteration at ~1.9 GHz
+    const int iters = (int)((double)ms_target * 1e-3 * 1.9e9 / 256.0);
+    HIPCHK(h, mfma_probe(iters, (float*)h->enc_flag, (hipStream_t)stream, tflops, mhz));
+    return MNX_OK;
 }
 
 int mnx_profile_enable(mnx_engine* h, int32_t enable) {

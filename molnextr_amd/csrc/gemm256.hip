@@ -358,6 +358,11 @@ __device__ unsigned long long x3_lab_stamps[256 * 8];
 #ifndef MNX_X3_STAGGER
 #define MNX_X3_STAGGER 0
 #endif
+// Effective shader clock of the launches (measurement aid, always compiled): workgroup 0 adds its lifetime in shader cycles
+// (s_memtime) and in 100 MHz ticks (s_memrealtime) to two counters; x3_clock_read() turns them into MHz. The chip clocks to
+// its power budget — 1.65-1.9 GHz under this kernel with real operands, 2.39 GHz on zeros (profiles/r05_gemm_lab_ablations.txt)
+// — so a rate only means something next to the clock it was reached at. Cost: four scalar instructions per launch.
+__device__ unsigned long long x3_clk_acc[2];
 
 // fp32 epilogue forms 1 / 2: vector-memory operations younger than the residual loads of slab mt when they are waited for
 // (4 loads + 4 stores per slab, four slabs of loads in flight): 12 16 20 24 24 20 16 12
@@ -453,6 +458,8 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (blockIdx.x == 0) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
 #if MNX_X3_STAGGER
     {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -797,6 +804,10 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     }
 #undef MNX_X3_WAIT
     if (wr == 0) __builtin_amdgcn_s_barrier();    // the first wave row waits for the second one's last segment
+    if (blockIdx.x == 0 && tid == 0) {
+        atomicAdd(&x3_clk_acc[0], (unsigned long long)__builtin_readcyclecounter() - clk_c0);
+        atomicAdd(&x3_clk_acc[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
 #if MNX_X3_LAB & 16
     if (lane == 0 && (wave == 0 || wave == 4)) {
         unsigned long long* o = x3_lab_stamps + blockIdx.x * 8 + (wave >> 2) * 4;
@@ -866,6 +877,71 @@ hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, vo
 #undef MNX_G256X3_TYPE
 #undef MNX_G256X3_CASE
     return hipGetLastError();
+}
+
+// shader clock (MHz) averaged over the gemm256x3_kernel launches since the last reset (0 when there were none)
+hipError_t x3_clock_read(double* mhz, bool reset) {
+    unsigned long long acc[2] = {0, 0};
+    hipError_t e = hipMemcpyFromSymbol(acc, HIP_SYMBOL(x3_clk_acc), sizeof(acc));
+    if (e != hipSuccess) return e;
+    *mhz = acc[1] ? (double)acc[0] / (double)acc[1] * 100.0 : 0.0;
+    if (reset) { acc[0] = acc[1] = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(x3_clk_acc), acc, sizeof(acc)); }
+    return e;
+}
+
+// ---- what the matrix pipes sustain on random operands (tools/probes/mfma_power.hip as a library call): register-only loop of
+// v_mfma_f32_16x16x32_f16, 8 accumulators per wave, 8 waves per CU on every CU, operands rotating through four A and four B
+// registers of random fp16 numbers; no LDS, no memory. The honest ceiling of any fp16 MFMA kernel on THIS device under THIS
+// power budget: 1.93 PFLOP/s at 1.89 GHz where the nominal peak says 2.5 at 2.4 (profiles/r05_mfma_power.txt).
+namespace {
+__device__ unsigned long long mfma_probe_clk[2];
+__global__ __launch_bounds__(512) void mfma_probe_kernel(float* out, int iters) {
+    typedef H16<f16_t>::v8 v8;
+    v8 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) {
+            unsigned h = ((threadIdx.x * 8 + i) * 16 + j + blockIdx.x * 65536) * 2654435761u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            a[i][j] = (f16_t)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.f));
+            b[i][j] = (f16_t)(((int)(h >> 16) - 32768) * (1.0f / 32768.f));
+        }
+    unsigned long long c0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = H16<f16_t>::mfma(a[i & 3], b[(i >> 1) & 3], acc[i]);
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        mfma_probe_clk[0] = (unsigned long long)__builtin_readcyclecounter() - c0;
+        mfma_probe_clk[1] = (unsigned long long)__builtin_amdgcn_s_memrealtime() - r0;
+    }
+    if (sum == 12345.678f) out[0] = sum;      // never true: keeps the loop alive
+}
+}  // namespace
+
+hipError_t mfma_probe(int iters, float* scratch, hipStream_t s, double* tflops, double* mhz) {
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { hipEventDestroy(e0); return e; }
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(512), 0, s, scratch, iters / 8 + 1);    // power management settles
+    hipEventRecord(e0, s);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(512), 0, s, scratch, iters);
+    hipEventRecord(e1, s);
+    e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long clk[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(clk, HIP_SYMBOL(mfma_probe_clk), sizeof(clk));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (e != hipSuccess) return e;
+    *tflops = 256.0 * 8.0 * (double)iters * 8.0 * (16.0 * 16.0 * 32.0 * 2.0) / ((double)ms * 1e-3) * 1e-12;
+    *mhz = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0;
+    return hipSuccess;
 }
 
 #if MNX_X3_LAB & 16

@@ -18,12 +18,12 @@ from . import weights as W
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmolnextr_hip.so")
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
            "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess",
            "mnx_probe_decode_attn", "mnx_predict_beam", "mnx_set_split_terms", "mnx_encoder_status",
-           "mnx_gemm16_split", "mnx_decode_forced")
+           "mnx_gemm16_split", "mnx_decode_forced", "mnx_gemm_clock", "mnx_probe_mfma")
 
 # Encoder operand modes (include/molnextr_hip.h MNX_DTYPE_*). "fp16x3" — split fp16 operands, three MFMA terms per
 # product, fp32-class results — is the default: it is the fastest mode whose tokens / atoms / bonds equal the reference's.
@@ -112,6 +112,10 @@ def load_library():
     lib.mnx_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.mnx_probe_decode_attn.restype = C.c_int
     lib.mnx_probe_decode_attn.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    lib.mnx_gemm_clock.restype = C.c_int
+    lib.mnx_gemm_clock.argtypes = [vp, i32, C.POINTER(C.c_double)]
+    lib.mnx_probe_mfma.restype = C.c_int
+    lib.mnx_probe_mfma.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     lib.mnx_set_token_classes.restype = C.c_int
     lib.mnx_set_token_classes.argtypes = [vp, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     lib.mnx_atom_scan.restype = C.c_int
@@ -423,6 +427,19 @@ class Engine:
         self._check(self.lib.mnx_probe_decode_attn(self.h, rows, t, iters, C.byref(a), C.byref(b), _stream()),
                     "mnx_probe_decode_attn")
         return a.value, b.value
+
+    def gemm_clock(self, reset: bool = True) -> float:
+        """Shader clock (MHz) averaged over the persistent split-operand GEMM launches since the last reset (0.0: none ran)."""
+        mhz = C.c_double()
+        self._check(self.lib.mnx_gemm_clock(self.h, int(reset), C.byref(mhz)), "mnx_gemm_clock")
+        return mhz.value
+
+    def probe_mfma(self, ms: int = 30):
+        """(TFLOP/s, MHz) of a register-only fp16 MFMA loop on random operands on every CU: what the matrix pipes sustain
+        under this device's power budget."""
+        tf, mhz = C.c_double(), C.c_double()
+        self._check(self.lib.mnx_probe_mfma(self.h, ms, C.byref(tf), C.byref(mhz), _stream()), "mnx_probe_mfma")
+        return tf.value, mhz.value
 
     def gemm16_split(self, epi: int, A2: torch.Tensor, W2: torch.Tensor, Cout: torch.Tensor,
                      bias: Optional[torch.Tensor], oscale: float = 1.0, terms: int = 3):

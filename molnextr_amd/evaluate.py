@@ -72,6 +72,11 @@ def dumps_field(obj) -> Optional[str]:
 PAD_TO_SQUARE_FILES = ("real/acs.csv", "real/UOB.csv")     # reference dataset.py:163-164
 
 
+class RangeFallback(RuntimeError):
+    """Raised by run_inference on EVERY rank when any rank's encoder left the fp16 range of the operand mode: the caller
+    rebuilds its engine in the fallback mode (engine.RANGE_FALLBACK) and repeats the whole evaluation."""
+
+
 def run_inference(engine, load_image: Callable[[int], np.ndarray], n_items: int, batch_size: int, rank: int = 0,
                   world: int = 1, tokenizer=None, group: int = 512, pad_to_square: bool = False) -> Dict[int, dict]:
     """valid_fn for this rank's shard, then the gather: returns {dataset index: prediction dict} on every rank
@@ -87,12 +92,26 @@ def run_inference(engine, load_image: Callable[[int], np.ndarray], n_items: int,
     recs = []
     step = max(group // ref_batch, 1) * ref_batch          # whole reference batches per engine call
     dev = getattr(engine, "torch_device", None) or torch.device("cuda", engine.device)
-    for g0 in range(0, len(mine), step):
-        ids = mine[g0:g0 + step]
-        x = engine.preprocess([load_image(i) for i in ids], pad_to_square=pad_to_square)
-        out = engine.predict(x, ref_batch=ref_batch)
-        recs.append(shard.pack_records_device(out["tokens"], out["lengths"], out["atom_idx"], out["n_atoms"],
-                                              out["edges"]))
+    # An activation beyond the fp16 range of the operand mode ends THIS rank's shard with MNX_ERR_RANGE. Every rank must then
+    # repeat its shard in the fallback mode — one predictions table must not mix operand modes, and a rank that restarts
+    # alone would leave its peers waiting in the gather —, so the ranks agree on "somebody saw a range error" (one scalar
+    # all-reduce MAX) BEFORE the gather and raise together.
+    from .engine import MnxError, range_fallback_dtype
+    range_err = None
+    try:
+        for g0 in range(0, len(mine), step):
+            ids = mine[g0:g0 + step]
+            x = engine.preprocess([load_image(i) for i in ids], pad_to_square=pad_to_square)
+            out = engine.predict(x, ref_batch=ref_batch)
+            recs.append(shard.pack_records_device(out["tokens"], out["lengths"], out["atom_idx"], out["n_atoms"],
+                                                  out["edges"]))
+    except MnxError as err:
+        if range_fallback_dtype(err, getattr(engine, "dtype", None)) is None:
+            raise
+        range_err = err
+    seen = shard.any_rank(range_err is not None, dev) if world > 1 else range_err is not None
+    if seen:
+        raise RangeFallback(str(range_err) if range_err is not None else "another rank's encoder left the fp16 operand range")
     rec = torch.cat(recs) if recs else torch.zeros(0, shard.record_words(kmax), dtype=torch.int32, device=dev)
     index = torch.tensor(mine, dtype=torch.int32, device=dev).view(-1, 1)
     rec = torch.cat([index, rec], dim=1).contiguous()      # the dataset index travels with its record
@@ -193,13 +212,14 @@ def main(argv=None):
                              pad_to_square=args.test_file in PAD_TO_SQUARE_FILES)
     try:
         preds = infer(engine)
-    except Exception as err:     # noqa: BLE001 - only the operand-range case is handled, everything else is re-raised
-        from .engine import range_fallback_dtype
-        to = range_fallback_dtype(err, dtype)
+    except RangeFallback as err:
+        # the reference evaluates any checkpoint; an activation beyond the fp16 range must not end the run. All ranks arrive
+        # here together (run_inference agrees on the flag before its gather): one table, one operand mode.
+        from .engine import RANGE_FALLBACK
+        to = RANGE_FALLBACK.get(dtype)
         if to is None:
             raise
-        # the reference evaluates any checkpoint; an activation beyond the fp16 range must not end the run
-        print(f"[rank {rank}] {err}: repeating the evaluation with --dtype {to}", file=sys.stderr, flush=True)
+        print(f"[rank {rank}] {err}: repeating the evaluation with --dtype {to} on every rank", file=sys.stderr, flush=True)
         engine.close()
         engine = Engine(states["encoder"], states["decoder"], device=local, max_batch=64, dtype=to)
         preds = infer(engine)

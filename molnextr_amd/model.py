@@ -121,6 +121,10 @@ def predict_pipeline(engine: Engine, images: torch.Tensor, tokenizer=None, ref_b
     return preds
 
 
+class _RestartCall(Exception):
+    """Private: the facade's engine was rebuilt in the range-fallback mode after part of a call had been computed."""
+
+
 class molnextr:
     """Main interface (reference MolNexTR/model.py:33-196).
 
@@ -158,6 +162,8 @@ class molnextr:
         self.device_preprocess = device_preprocess
         self.group_images = 1024          # images per engine call of the throughput path (whole reference batches)
 
+    _groups_done = 0          # groups of the running predict_images call that have produced predictions
+
     def _with_fallback(self, job):
         """job(engine) -> result. When the engine reports that an activation left the fp16 range of its operand mode
         (MNX_ERR_RANGE: possible with fp16x3 / fp16 on checkpoints with very large activations), the engine is rebuilt ONCE
@@ -177,6 +183,10 @@ class molnextr:
             self.engine.close()
             self.engine = Engine(self._states["encoder"], self._states["decoder"], device=dev, max_batch=self._max_batch,
                                  dtype=to)
+            if self._groups_done:
+                # earlier groups of this predict_images call were computed in the fp16 mode: one call, one operand mode —
+                # the call starts again from its first image (predict_images catches this)
+                raise _RestartCall()
             return job(self.engine)
 
     @staticmethod
@@ -233,9 +243,21 @@ class molnextr:
             yield item
 
     def predict_images(self, input_images: List, return_atoms_bonds=False, return_confidence=False, batch_size=16):
-        preds: List[dict] = []
         if len(input_images) == 0:
             return []                                      # reference model.py:101-102: empty loop, empty list
+        try:
+            self._groups_done = 0
+            preds = self._predict_all(input_images, return_confidence, batch_size)
+        except _RestartCall:                               # the engine was rebuilt in the bf16 split mode after some groups
+            self._groups_done = 0
+            preds = self._predict_all(input_images, return_confidence, batch_size)
+        finally:
+            self._groups_done = 0
+        return self._assemble(preds, input_images, return_atoms_bonds, return_confidence)
+
+    def _predict_all(self, input_images: List, return_confidence: bool, batch_size: int) -> List[dict]:
+        """The engine part of predict_images: one prediction dict per image, every group in ONE operand mode."""
+        preds: List[dict] = []
         cap = min(ROWS, self.engine.max_batch)
         batch_size = min(batch_size, len(input_images))     # a batch larger than the job is the whole job: same numbering
         if batch_size < 1 or batch_size > cap:
@@ -250,6 +272,7 @@ class molnextr:
             for x in self._prefetched(groups):
                 preds += self._with_fallback(
                     lambda eng: predict_pipeline(eng, x, self.tokenizer, ref_batch_size=batch_size))
+                self._groups_done += 1
         else:
             step = max(self.engine.max_batch // batch_size, 1) * batch_size
             for i in range(0, len(input_images), step):
@@ -263,6 +286,11 @@ class molnextr:
                                        f"mode '{eng.dtype}'", code=MNX_ERR_RANGE)
                     return decode_batch(eng, feats, self.tokenizer, ref_batch_size=batch_size, compute_confidence=True)
                 preds += self._with_fallback(conf_job)
+                self._groups_done += 1
+        return preds
+
+    def _assemble(self, preds: List[dict], input_images: List, return_atoms_bonds: bool, return_confidence: bool):
+        """Output dicts of predict_images (reference model.py:111-196) from the per-image predictions."""
         from .chem import convert_graph_to_smiles
         smiles_list, molblock_list, _ = convert_graph_to_smiles(
             [p["chartok_coords"]["coords"] for p in preds], [p["chartok_coords"]["symbols"] for p in preds],

@@ -93,3 +93,13 @@ def gather_records(rec: torch.Tensor, force: bool = False) -> torch.Tensor:
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec.contiguous())
     return out
+
+
+def any_rank(flag: bool, device) -> bool:
+    """True on every rank when `flag` is true on at least one (one scalar all-reduce MAX; a plain bool without a process
+    group). evaluate.run_inference uses it so that all ranks leave the fp16 operand mode together."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())

@@ -1,4 +1,4 @@
-"""CPU: the operand-mode emulation of tests/study_split_terms.py (the tool behind DESIGN.md's split-term / FP8 table) on a
+"""CPU: the operand-mode emulation of tools/study_split_terms.py (the tool behind DESIGN.md's split-term / FP8 table) on a
 tiny Swin: its fp32 scheme IS the oracle, and the schemes order as the arithmetic says they must."""
 import os
 import sys
@@ -10,7 +10,7 @@ from molnextr_amd import weights as W
 from oracle.config import SwinConfig
 from oracle.swin import encoder_forward
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
 import study_split_terms as ST  # noqa: E402
 
 TINY_W = W.EncoderDims(img_size=96, patch=4, embed_dim=32, depths=(2, 2), heads=(1, 2), window=12)

@@ -31,12 +31,19 @@ __device__ __forceinline__ f16x8 rnd8(unsigned seed, float scale) {
 }
 
 // MODE 0: 16x16x32, 8 accumulators (32 registers); MODE 1: 32x32x16, 2 accumulators (32 registers). Same flop per iteration.
+// bmask / bscale: the B operand as a "lo plane" — scaled down by bscale and with its low mantissa bits cleared (AND with bmask):
+// does an operand with fewer significant bits cost less power?
 template <int MODE>
-__global__ __launch_bounds__(512) void loop(float* out, int iters, float scale) {
+__global__ __launch_bounds__(512) void loop(float* out, int iters, float scale, unsigned bmask = 0xffffu, float bscale = 1.f) {
     f16x8 a[4], b[4];
     for (int i = 0; i < 4; ++i) {
         a[i] = rnd8((threadIdx.x * 8 + i) * 16 + blockIdx.x * 65536, scale);
-        b[i] = rnd8((threadIdx.x * 8 + 4 + i) * 16 + blockIdx.x * 65536, scale);
+        b[i] = rnd8((threadIdx.x * 8 + 4 + i) * 16 + blockIdx.x * 65536, scale * bscale);
+        for (int j = 0; j < 8; ++j) {
+            unsigned short u = __builtin_bit_cast(unsigned short, b[i][j]);
+            u &= (unsigned short)bmask;
+            b[i][j] = __builtin_bit_cast(_Float16, u);
+        }
     }
     unsigned long long c0 = 0, r0 = 0;
     if (threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -101,5 +108,26 @@ int main() {
                 printf("%-12s %-8s %5d %6d | %8.2f %9.1f %8.3f | %6.0f  %5.2f\n", mode == 0 ? "16x16x32" : "32x32x16", scale == 0.f ? "zero" : "random",
                        cus, waves, ms, tf, tf / 2500.0 * 256.0 / cus, clk, ms * 1e-3 * clk * 1e6 / n_inst_per_simd);
             }
+    // the B operand as a lo plane: 2^-11 of A's size, mantissa cut to 10 / 6 / 4 / 2 / 0 stored bits (16x16x32, 256 CUs)
+    printf("\nB operand as a lo plane (x 2^-11), low mantissa bits cleared; 16x16x32, 256 CUs x 8 waves\n");
+    for (unsigned keep : {10u, 6u, 4u, 2u, 0u}) {
+        const unsigned mask = 0xffffu & ~((1u << (10 - keep)) - 1u);
+        hipLaunchKernelGGL(loop<0>, dim3(256), dim3(512), 0, 0, out, 20000, 1.f, mask, 1.f / 2048.f);
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(loop<0>, dim3(256), dim3(512), 0, 0, out, iters, 1.f, mask, 1.f / 2048.f);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> hs(512);
+        (void)hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(stamps), sizeof(unsigned long long) * 512);
+        std::vector<double> mhz;
+        for (int w = 0; w < 256; ++w) if (hs[2 * w + 1]) mhz.push_back((double)hs[2 * w] / (double)hs[2 * w + 1] * 100.0);
+        std::sort(mhz.begin(), mhz.end());
+        const double flop = 256.0 * 8 * iters * 8.0 * 16.0 * 16.0 * 32.0 * 2.0;
+        printf("  stored mantissa bits %2u (mask 0x%04x): %8.2f ms  %8.1f TFLOP/s  clock %.0f MHz\n", keep, mask, ms, flop / (ms * 1e-3) * 1e-12,
+               mhz.empty() ? 0.0 : mhz[mhz.size() / 2]);
+    }
+    // the same with A masked too would be the hi.hi term of bf16-like operands: A and B with 7 stored mantissa bits
     return 0;
 }
