@@ -352,12 +352,13 @@ def main():
     ap.add_argument("--max-len", type=int, default=480)
     ap.add_argument("--dtype", default="fp16x3", choices=["fp16x3", "bf16x3", "bf16", "fp16", "fp32"],
                     help="encoder operand mode; fp16x3 (default) is the fastest one that is token-exact vs the reference")
-    ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "448")),
-                    help="images per encoder launch group (a multiple of 32; decode batches stay 32). 448 = 14 reference "
-                         "batches = 2 x 224: the N = 512 / 1024 layers of Swin stages 3 / 4 have 2016 / 1008 output tiles of "
-                         "256x256 = 7.9 / 3.9 rounds over 256 CUs (224 images: 3.94 / 1.97; 128: 2.25 / 1.125). Measured "
-                         "(round 4, one box): 1756 molecules/s at 448, 1726-1732 at 224, 1739-1745 at 320, 1755 at 640 on the "
-                         "driver's command; 2134 vs 2111 at 512 steps")
+    ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "512")),
+                    help="images per encoder launch group (a multiple of 32; decode batches stay 32). 512 = 16 reference "
+                         "batches: every Linear of Swin stage 3 then has a WHOLE number of rounds of 256 output tiles of 256x256 "
+                         "(proj / fc2 2304 = 9 x 256, qkv 6912 = 27 x 256, fc1 9216 = 36 x 256; at 448 images 7.875 / 23.6 / 31.5 "
+                         "rounds: a ragged last round, the rest on the 128x128 kernel). Measured (round 5, one box, alternating): "
+                         "1782 / 1785 molecules/s at 512, 1762 / 1768 at 448, 1762 / 1765 at 640, 1750 / 1746 at 320 on the "
+                         "driver's command; 2173 vs 2172 at 512 steps (1024: 2057)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MNX_SLOTS", "3072")),
                     help="sequences resident in the decoder (multiple of 32, <= 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

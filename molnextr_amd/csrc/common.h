@@ -120,7 +120,7 @@ __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast4((f32x4){
 // gemm256x3_kernel. gelu_poly16 is the construction of gelu_fast4 carried to fp32 accuracy: x * Phi(x),
 // Phi = 0.5 + xc * Q(u), xc = clamp(x, +-5.5), u = 2 xc^2 / 5.5^2 - 1, Q the degree-16 Chebyshev fit of (Phi(x) - 0.5) / x in
 // monomials of u, every step one FMA (packed: two values per instruction). Against the exact function its error is
-// <= 1.3e-7 max(1, |x|) (rms 1.6e-8) — the formula the reference evaluates, 0.5 x (1 + erf(x / sqrt 2)) in fp32 with a
+// <= 1.3e-7 max(1, |x|) (rms 2e-8) — the formula the reference evaluates, 0.5 x (1 + erf(x / sqrt 2)) in fp32 with a
 // correctly rounded erf, has 1.1e-7 max(1, |x|) (rms 1.2e-8): tests/test_device_math.py checks both numbers. x < -5.5 returns
 // -5.5 Phi(-5.5) = -1.0e-7 (exact: -> 0). Every split-mode epilogue (gemm256.hip, gemm.hip) uses the same function, so an
 // image's features stay independent of which kernel a row lands in.

@@ -814,9 +814,9 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
     const int D = 256, H = w.heads, T = b.T;
     int stage = 0;      // stage k reads stream k & 1 and partial buffer (k - 1) & 1, writes stream / partials (k + 1) & 1 / k & 1
     float* xb[2] = {b.x, b.x2};
-    float* pb[2] = {b.fpart, b.fpart + (size_t)16 * b.slots * D};
+    float* pb[2] = {b.fpart, b.fpart + (size_t)16 * b.fpart_rows * D};
     FusedArgs a = {};
-    a.st = b.st; a.part_stride = b.slots * D; a.T = T; a.heads = H; a.emb = w.emb; a.pe = w.pe; a.S = b.S; a.dff = w.dff;
+    a.st = b.st; a.part_stride = b.fpart_rows * D; a.T = T; a.heads = H; a.emb = w.emb; a.pe = w.pe; a.S = b.S; a.dff = w.dff;
     a.mem_stride = (long long)b.S * w.layers * 2 * D;
     a.stamps = g_stamps;
     a.row_base = row_base;
@@ -866,7 +866,8 @@ hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, in
     const bool mid = row_tile >= 2000;       // 2000 + 100 R + RC: the mid form (dec_ma + dec_mb instead of dec_fa)
     const int xcd = (row_tile / 1000) & 1;   // 1000 + 100 R + RC: XCD-local row tiles (FusedArgs::xcd)
     row_tile %= 1000;
-    if (w.dff != 16 * FF_SLICE || w.heads != 8 || b.T + 1 > PS_SELF || b.S > PS_CROSS || (rows % 16) || !b.fpart)
+    if (w.dff != 16 * FF_SLICE || w.heads != 8 || b.T + 1 > PS_SELF || b.S > PS_CROSS || (rows % 16) || !b.fpart ||
+        row_base + rows > b.fpart_rows)
         return hipErrorInvalidValue;
     switch (row_tile) {
         case 204: fused_layers<2, 4>(w, b, row_base, rows, xcd, mid, s); break;
@@ -878,7 +879,7 @@ hipError_t dec_enqueue_fused_layers(const DecWeights& w, const DecBuffers& b, in
     }
     const int stages = 3 * w.layers;
     *x_final = (stages & 1) ? b.x2 : b.x;
-    *part_final = b.fpart + (size_t)((stages - 1) & 1) * 16 * b.slots * 256;
+    *part_final = b.fpart + (size_t)((stages - 1) & 1) * 16 * b.fpart_rows * 256;
     return hipGetLastError();
 }
 

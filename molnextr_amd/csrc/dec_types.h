@@ -67,7 +67,8 @@ struct DecBuffers {
     DecState* st;
     float *x, *q, *ctx, *h;                    // [slots,256] x3, [slots,1024]
     float *x2, *part;                          // the other residual-stream buffer [slots,256]; w_2 K-slice partials [dff/256][slots,256]
-    float *fpart;                              // fused tick (dec_fused.hip): two alternating partial buffers [2][16][slots,256]
+    float *fpart;                              // fused tick (dec_fused.hip): two alternating partial buffers [2][16][fpart_rows,256]
+    int fpart_rows;                            // rows a plane holds = the largest capacity that runs fused / mid (<= slots)
     float *self_k, *self_v;                    // [layers, slots, heads, T, 32]
     float *memory;                             // [32*S, 256]   scratch of one admission
     float *mem_kv;                             // [mem_blocks, layers, K|V, heads, S, 32]

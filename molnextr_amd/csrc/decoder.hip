@@ -817,7 +817,7 @@ hipError_t dec_enqueue_tick_rows(const DecWeights& w, const DecBuffers& b, int r
     HeadArgs h = {};
     h.x = (split_w2 && ((w.layers - 1) & 1)) ? b.x2 : b.x; h.part = split_w2 ? b.part : nullptr; h.part_stride = b.slots * D;
     h.n_part = w.dff / 256;
-    if (fused) { h.x = fx; h.part = fp; h.tree_bias = w.L[w.layers - 1].b2; h.xcd = (((fused_tile / 1000) & 1) && fused_tile < 2000 && rows % 32 == 0) ? 1 : 0; } h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
+    if (fused) { h.x = fx; h.part = fp; h.part_stride = b.fpart_rows * D; h.tree_bias = w.L[w.layers - 1].b2; h.xcd = (((fused_tile / 1000) & 1) && fused_tile < 2000 && rows % 32 == 0) ? 1 : 0; } h.gamma = w.lnF_g; h.beta = w.lnF_b; h.wout_t = w.wout_t; h.bout = w.bout; h.st = b.st;
     h.tokens = b.tokens; h.token_logp = b.logp; h.hidden = b.hidden; h.logits_trace = logits_trace;
     h.V = w.vocab; h.VP = w.vpad; h.T = T; h.x0 = w.sym_offset; h.y0 = w.sym_offset + w.bins;
     h.eos = 2; h.trace_rows = trace_rows; h.forced = forced; h.row_base = row_base;

@@ -581,8 +581,13 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     db.x = (float*)P.dalloc((size_t)SL * D * 4);
     db.x2 = (float*)P.dalloc((size_t)SL * D * 4);
     db.part = (float*)P.dalloc((size_t)(FF / 256) * SL * D * 4);
-    db.fpart = (float*)P.dalloc((size_t)2 * 16 * SL * D * 4);
-    if (db.fpart && hipMemset(db.fpart, 0, (size_t)2 * 16 * SL * D * 4) != hipSuccess) P.problems.push_back("hipMemset failed");
+    // partial planes of the fused / mid tick: only ticks of up to max(dec_fused_max, dec_mid_max) rows of capacity touch them
+    // (128 rows by default: 4 MB; every slot would be 100 MB at the bench's 3072)
+    // (tick branches — off by default — run fused tiles at any row offset of a larger tick: every slot then)
+    db.fpart_rows = h->dec_branch_rows > 0 ? SL
+                  : std::min(SL, std::max(ROW_TILE, (std::max(h->dec_fused_max, h->dec_mid_max) + ROW_TILE - 1) / ROW_TILE * ROW_TILE));
+    db.fpart = (float*)P.dalloc((size_t)2 * 16 * db.fpart_rows * D * 4);
+    if (db.fpart && hipMemset(db.fpart, 0, (size_t)2 * 16 * db.fpart_rows * D * 4) != hipSuccess) P.problems.push_back("hipMemset failed");
     if (dec_fused_init() != hipSuccess) P.problems.push_back("dec_fused_init: LDS opt-in failed");
     db.q = (float*)P.dalloc((size_t)SL * D * 4);
     db.ctx = (float*)P.dalloc((size_t)SL * D * 4);
@@ -613,11 +618,13 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&h->enc_stream, hipStreamNonBlocking, hi) != hipSuccess) P.problems.push_back("stream create failed");
         if (hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) != hipSuccess) P.problems.push_back("event create failed");
-        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) P.problems.push_back("event create failed");
-        for (int i = 1; i < MAX_TICK_BRANCHES; ++i)
-            if (hipStreamCreateWithFlags(&h->tick_streams[i], hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess)
-                P.problems.push_back("tick branch stream / event create failed");
+        if (h->dec_branch_rows > 0) {       // tick branches (off by default): their streams / events only when asked for
+            if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) P.problems.push_back("event create failed");
+            for (int i = 1; i < MAX_TICK_BRANCHES; ++i)
+                if (hipStreamCreateWithFlags(&h->tick_streams[i], hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess)
+                    P.problems.push_back("tick branch stream / event create failed");
+        }
     }
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&h->ev_enc_done[i], hipEventDisableTiming) != hipSuccess ||
@@ -776,7 +783,7 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
 static int tick_tile(const mnx_engine* h, int rows) {
     const mnx_config& c = h->cfg;
     if (c.dec_ff != 1024 || c.dec_heads != 8 || c.dec_dim != 256 || c.max_len + 1 > 512 || h->db.S > 160) return 0;
-    if (h->dec_tile == 0 || rows % 16) return 0;
+    if (h->dec_tile == 0 || rows % 16 || rows > h->db.fpart_rows) return 0;
     if (rows > h->dec_fused_max) {      // mid form: 4-row attention tiles, 16-row feed-forward tiles
         if (rows > h->dec_mid_max) return 0;
         return 2000 + 100 * 4 + 16;

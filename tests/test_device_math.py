@@ -45,6 +45,42 @@ def test_polynomial_gelu_of_the_gemm_epilogues_vs_exact_erf_gelu():
     assert got[np.argmax(x == 0)] == 0.0
 
 
+def test_degree16_polynomial_gelu_is_as_accurate_as_the_reference_formula():
+    """gelu_poly16 (common.h; lab option MNX_GELU_POLY of the split-mode epilogues, measured: no faster on the power-limited
+    GEMMs): x Phi(x) with Phi = 0.5 + xc Q(u), xc = clamp(x, +-5.5), u = 2 xc^2 / 5.5^2 - 1, Q of degree 16, every
+    step one FMA. Its header claims an error of <= 1.3e-7 max(1, |x|) against the exact function — as good as the formula the
+    reference evaluates, 0.5 x (1 + erf(x / sqrt 2)) in fp32 with a correctly rounded erf (1.1e-7 max(1, |x|))."""
+    src = open(os.path.join(ROOT, "molnextr_amd", "csrc", "common.h")).read()
+    body = src[src.index("f32x4 gelu_poly16(f32x4 x) {"):]
+    body = body[:body.index("\n}\n")]
+    lead = re.search(r"q = u \* ([-0-9.e+]+)f \+ ([-0-9.e+]+)f;", body)
+    rest = re.findall(r"q = q \* u \+ ([-0-9.e+]+)f;", body)
+    coef = [float(lead.group(1)), float(lead.group(2))] + [float(c) for c in rest]
+    assert len(coef) == 17 and "-5.5f, 5.5f" in body and "xo * (xc * q + 0.5f)" in body
+    scale = float(re.search(r"xc \* xc \* ([-0-9.e+]+)f - 1.0f", body).group(1))
+    assert abs(scale - 2.0 / 5.5 ** 2) < 1e-9
+    f = np.float32
+
+    def fma(a, b, c):        # a * b is exact in float64 for float32 inputs: one rounding, as the hardware FMA
+        return (a.astype(np.float64) * b.astype(np.float64) + np.float64(c)).astype(f)
+    x = np.concatenate([np.linspace(-8, 8, 1600001), np.random.default_rng(0).normal(size=400000) * 1.5]).astype(f)
+    xc = np.clip(x, f(-5.5), f(5.5))
+    u = fma(xc * xc, np.full_like(x, f(scale)), f(-1.0))
+    q = fma(u, np.full_like(x, f(coef[0])), f(coef[1]))
+    for c in coef[2:]:
+        q = fma(q, u, f(c))
+    got = (np.maximum(x, f(-5.5)) * fma(xc, q, f(0.5))).astype(np.float64)
+    x64 = x.astype(np.float64)
+    want = 0.5 * x64 * (1.0 + erf(x64 / np.sqrt(2.0)))
+    scale_x = np.maximum(1.0, np.abs(x64))
+    err = np.abs(got - want) / scale_x
+    e32 = erf((x * f(0.7071067811865476)).astype(np.float64)).astype(f)
+    ref = ((f(0.5) * x) * (f(1) + e32)).astype(np.float64)
+    err_ref = np.abs(ref - want) / scale_x
+    assert err.max() < 1.4e-7 and err_ref.max() < 1.2e-7, (err.max(), err_ref.max())
+    assert np.sqrt((err ** 2).mean()) < 3.0e-8
+
+
 def test_gemm256_vmcnt_bookkeeping_constants():
     """The counted waits of gemm256.hip are derived from how many vector-memory operations a wave issues per tile;
     the constants the derivation uses must match the code that issues them."""

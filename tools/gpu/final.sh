@@ -1,6 +1,8 @@
 #!/bin/bash
-# round-end pass: the whole GPU suite, smoke(), the driver's bench command (full line, with sub-results and the CPU baseline),
-# the default bench, the rocprofv3 profiles of tools/gpu/profiles.sh, then the fused tick's phase stamps (lab build of the library)
+# round-end pass: the whole GPU suite, smoke(), the rocprofv3 profiles of tools/gpu/profiles.sh (kernel stats + tick profile of
+# the driver's command, the two PMC passes whose traffic figure the bench lines AFTER them report — same kernels, same box),
+# the driver's bench command (full line, with sub-results and the CPU baseline), the default bench, the GEMM shape tables of
+# tools/gemm_lab and the tick-time table of tools/tick_time.py, then the fused tick's phase stamps (lab build of the library)
 cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -8,16 +10,20 @@ rm -f gpurun_out/pixels_parity.json
 timeout 1800 python -m pytest tests -x -q -m gpu > gpurun_out/t_gpu.log 2>&1; echo "pytest rc=$?"
 tail -4 gpurun_out/t_gpu.log | cut -c1-300
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log
+bash tools/gpu/profiles.sh
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_full20.log 2>&1; echo "bench20 rc=$?"; tail -1 gpurun_out/bench_full20.log | cut -c1-300
 timeout 600 python bench.py --no-cpu-baseline --no-sub > gpurun_out/bench_default.log 2>&1; echo "bench default rc=$?"; tail -1 gpurun_out/bench_default.log | cut -c1-200
-bash tools/gpu/profiles.sh
+for b in 448 512; do
+  timeout 600 tools/gemm_lab/lab $b 20 - fp16x3 > gpurun_out/r05_gemm_shapes_fp16x3_b$b.txt 2>&1; echo "lab $b rc=$?"
+done
+timeout 600 python tools/tick_time.py 64,128,192,256,384,512,640 unfused,fused 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_tick_time.txt; echo "tick_time rc=$?"
 if [ -f tools/ab/libmolnextr_hip_stamps.so ]; then
   cp molnextr_amd/lib/libmolnextr_hip.so /tmp/mnx_cur.so
   cp tools/ab/libmolnextr_hip_stamps.so molnextr_amd/lib/libmolnextr_hip.so
   for cfg in "64 250 2 4" "128 250 4 4"; do
     set -- $cfg
     MNX_FUSED_STAMPS=/tmp/st_$1_$3.bin timeout 300 python tools/fused_stamps.py run $1 $2 $3 $4 2>&1 | grep -v amdgpu.ids
-    python tools/fused_stamps.py show /tmp/st_$1_$3.bin > gpurun_out/r04_fused_stamps_rows$1_tile$3.txt
+    python tools/fused_stamps.py show /tmp/st_$1_$3.bin > gpurun_out/r05_fused_stamps_rows$1_tile$3.txt
   done
   cp /tmp/mnx_cur.so molnextr_amd/lib/libmolnextr_hip.so
 fi

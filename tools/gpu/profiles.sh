@@ -3,7 +3,7 @@
 # WRITE_SIZE: separate passes) over plain encodes of one launch group, and the decode-tick view of the same trace
 cd /root/repo
 R=$GRAFT_REPO_ROOT
-EB=${EB:-448}
+EB=${EB:-512}
 DT=${DT:-fp16x3}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
