@@ -72,8 +72,28 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
             }
         }
         __syncthreads();
+        constexpr int NIT = ROWS * CH_ROW / 256;
+        // In-place residual (resid may alias Cout): written as "load, add, store" per iteration, the compiler has to keep every
+        // load behind the previous iteration's store — the generated code was eight serial memory round trips per thread, each
+        // wait also sitting out the previous store's acknowledgement. An element is read and written by the same thread in the
+        // same iteration and the iterations touch different addresses, so ALL residual loads are issued first (8 x 16 bytes
+        // per thread in flight), then the adds and stores: the same additions, one round trip.
+        f32x4 res[EPI == EPI_RESID_F32 ? NIT : 1];
+        if (EPI == EPI_RESID_F32) {
 #pragma unroll
-        for (int i = 0; i < ROWS * CH_ROW / 256; ++i) {
+            for (int i = 0; i < NIT; ++i) {
+                const int id = tid + i * 256;
+                const int rl = id / CH_ROW, ch = id % CH_ROW;
+                const int m = m0 + pass * ROWS + rl;
+                const int n = n0 + ch * (16 / ELT);
+                // unconditional (clamped to the matrix: an out-of-range lane re-reads a valid element it never uses) — a
+                // predicated load is a branch, and the compiler waits for each branch's load on its own
+                const int mc = m < M ? m : M - 1, nc = n < N ? n : N - 4;
+                res[i] = *(const f32x4*)(resid + (size_t)mc * N + nc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
             const int id = tid + i * 256;
             const int rl = id / CH_ROW, ch = id % CH_ROW;
             const int m = m0 + pass * ROWS + rl;
@@ -85,7 +105,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
                     *(v8*)((T*)Cout + o) = v;
                 } else {
                     f32x4 v = *(const f32x4*)(smem + rl * ROWB + ch * 16);
-                    if (EPI == EPI_RESID_F32) v += *(const f32x4*)(resid + o);
+                    if (EPI == EPI_RESID_F32) v += res[i];
                     *(f32x4*)((float*)Cout + o) = v;
                 }
             }

@@ -927,17 +927,17 @@ hipError_t mfma_probe(int iters, float* scratch, hipStream_t s, double* tflops, 
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);
     if (e != hipSuccess) return e;
-    if ((e = hipEventCreate(&e1)) != hipSuccess) { hipEventDestroy(e0); return e; }
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return e; }
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(512), 0, s, scratch, iters / 8 + 1);    // power management settles
-    hipEventRecord(e0, s);
+    e = hipEventRecord(e0, s);
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(512), 0, s, scratch, iters);
-    hipEventRecord(e1, s);
-    e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     unsigned long long clk[2] = {0, 0};
     if (e == hipSuccess) e = hipMemcpyFromSymbol(clk, HIP_SYMBOL(mfma_probe_clk), sizeof(clk));
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (e != hipSuccess) return e;
     *tflops = 256.0 * 8.0 * (double)iters * 8.0 * (16.0 * 16.0 * 32.0 * 2.0) / ((double)ms * 1e-3) * 1e-12;
     *mhz = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0;
