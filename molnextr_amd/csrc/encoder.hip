@@ -126,19 +126,39 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restric
     }
     f32x4 v[NV];  // C <= 256 * NV
     float sum = 0.f;
+    // All NV loads of the row are issued before anything is waited for: written as "if (e < C) load", every load was a branch
+    // of its own and the compiler waited for each (NV serial memory round trips per row). The address is clamped into the row
+    // instead (a lane beyond C re-reads the row's last 16 bytes) and the value zeroed by a select.
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int e = lane * 4 + j * 256;
-        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (e < C) {
-            if (MERGE) {
-                const int p = e / Cin;
-                v[j] = *(const f32x4*)(src[p] + (e - p * Cin));
-            } else {
-                v[j] = *(const f32x4*)(src[0] + e);
-            }
-            sum += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        const int ec = e < C ? e : C - 4;
+        if (MERGE) {
+            const int p = ec / Cin;
+            v[j] = *(const f32x4*)(src[p] + (ec - p * Cin));
+        } else {
+            v[j] = *(const f32x4*)(src[0] + ec);
         }
+    }
+    // gamma / beta likewise (NV <= 4: 8 NV registers): loaded per chunk inside the store loop below, each chunk's wait for
+    // them also sat out the previous chunk's store acknowledgements (loads and stores retire through one in-order counter)
+    constexpr bool GB_EARLY = NV <= 4;
+    f32x4 gv[GB_EARLY ? NV : 1], bv[GB_EARLY ? NV : 1];
+    if (GB_EARLY) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = lane * 4 + j * 256;
+            const int ec = e < C ? e : C - 4;
+            gv[j] = *(const f32x4*)(gamma + ec);
+            bv[j] = *(const f32x4*)(beta + ec);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the scheduler would otherwise sink each load next to its first use again
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = lane * 4 + j * 256;
+        if (!(e < C)) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sum += v[j][0] + v[j][1] + v[j][2] + v[j][3];
     }
     const float mean = row_sum<LPR>(sum) / (float)C;
     float sq = 0.f;
@@ -157,7 +177,8 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restric
     for (int j = 0; j < NV; ++j) {
         const int e = lane * 4 + j * 256;
         if (e < C) {
-            const f32x4 g = *(const f32x4*)(gamma + e), bt = *(const f32x4*)(beta + e);
+            const f32x4 g = GB_EARLY ? gv[GB_EARLY ? j : 0] : *(const f32x4*)(gamma + e);
+            const f32x4 bt = GB_EARLY ? bv[GB_EARLY ? j : 0] : *(const f32x4*)(beta + e);
             const f32x4 o = v[j] * rstd * g + bt;
             if (y16) {
                 if (SPLIT) {

@@ -481,7 +481,14 @@ static hipError_t launch_t(int epi, const void* A, const void* W, void* C, const
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const double waves128 = (double)t128 / 512.0;
     const bool small = t128 < 512 || (waves128 < 3.0 && (waves128 - (long)waves128) > 0.0 && (waves128 - (long)waves128) < 0.6);
-    if ((small || N <= 128) && N >= 64) return launch_bn<T, 64, SPLIT>(epi, A, W, C, bias, resid, M, N, K, s, sp);   // N = 128: +10 %
+#ifdef MNX_TILE128_BN      // tools/gemm_lab: force one tile width for every shape (64 or 128)
+    if (MNX_TILE128_BN == 64 && N >= 64) return launch_bn<T, 64, SPLIT>(epi, A, W, C, bias, resid, M, N, K, s, sp);
+    if (MNX_TILE128_BN == 128) return launch_bn<T, 128, SPLIT>(epi, A, W, C, bias, resid, M, N, K, s, sp);
+#endif
+    // N = 128 (stage-1 proj / fc2): 64-column tiles (+10 % in round 2); with the residual loads of round 5 in flight together the
+    // K = 512 layer (fc2) is 6 % faster on 128-column tiles again, K = 128 (proj) the same on both (profiles/r05_gemm_lab_tile_width.txt)
+    const bool narrow = N <= 128 && K < 512;
+    if ((small || narrow) && N >= 64) return launch_bn<T, 64, SPLIT>(epi, A, W, C, bias, resid, M, N, K, s, sp);
     return launch_bn<T, 128, SPLIT>(epi, A, W, C, bias, resid, M, N, K, s, sp);
 }
 

@@ -161,3 +161,28 @@ def test_rank_cpu_sets_follow_the_device_topology():
     # fewer usable CPUs on the node than ranks sharing it: fall back to slices instead of an empty set
     assert bench.rank_cpus(3, [n0] * 4, {0, 1}) != []
     assert bench.pin_rank(0, 1) is None
+
+
+def test_traffic_figure_is_only_taken_from_a_file_made_with_these_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from rocprofv3 --pmc passes that cannot run inside a timed bench; bench.py quotes the file only
+    when it carries the digest of the kernel sources THIS tree has (tools/collect_traffic.py stamps the same digest)."""
+    import json
+    import runpy
+    have = bench.library_sha16()
+    assert len(have) == 16 and have == bench.library_sha16()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "library_sha16", lambda: have)
+    assert bench.gemm_traffic("fp16x3", 512)[0] is None                      # no file
+    (prof / "r05_gemm_traffic_fp16x3_b512.json").write_text(json.dumps({"hbm_bytes_per_launch": 123.4, "library_sha16": "0" * 16}))
+    val, why = bench.gemm_traffic("fp16x3", 512)
+    assert val is None and "refused" in why
+    (prof / "r05_gemm_traffic_fp16x3_b512.json").write_text(json.dumps({"hbm_bytes_per_launch": 123.4, "library_sha16": have}))
+    val, why = bench.gemm_traffic("fp16x3", 512)
+    assert val == 123 and have in why
+    # the collector computes the digest the same way (it is a script: run its digest lines on this tree)
+    src = open(os.path.join(ROOT, "tools", "collect_traffic.py")).read()
+    ns = {"__file__": os.path.join(ROOT, "tools", "collect_traffic.py"), "out": {}}
+    exec(src[src.index("# the kernel sources the counters were collected on"):src.index("json.dump(out, open(sys.argv[3]")], ns)
+    assert ns["out"]["library_sha16"] == have

@@ -111,3 +111,66 @@ def test_run_inference_index_bookkeeping_gloo(world, n):
     for rank, smiles, batches in got:
         assert smiles == want, f"rank {rank}"
         assert batches == E.reference_batches(E.sampler_indices(n, rank, world), batch_size=2), f"rank {rank}"
+
+
+# ---- the operand-range fallback is collective: one rank's MNX_ERR_RANGE makes EVERY rank raise before the gather --------
+class _RangeEngine(_FakeEngine):
+    """fp16x3 engine whose rank-1 instance reports an activation beyond the fp16 range; bf16x3 engines decode normally."""
+    def __init__(self, dtype, fail):
+        super().__init__()
+        self.dtype, self.fail = dtype, fail
+
+    def predict(self, x, ref_batch=32, max_len=None):
+        if self.fail and self.dtype == "fp16x3":
+            from molnextr_amd.engine import MNX_ERR_RANGE, MnxError
+            raise MnxError("mnx_predict failed (-6): encoder features are not finite", code=MNX_ERR_RANGE)
+        return super().predict(x, ref_batch, max_len)
+
+
+def _range_worker(rank, world, n, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    raised = False
+    try:
+        E.run_inference(_RangeEngine("fp16x3", fail=(rank == 1)), _page, n, batch_size=2, rank=rank, world=world, group=8)
+    except E.RangeFallback:
+        raised = True
+    # every rank rebuilds in the fallback mode and repeats: one table, one operand mode
+    preds = E.run_inference(_RangeEngine("bf16x3", fail=(rank == 1)), _page, n, batch_size=2, rank=rank, world=world, group=8)
+    q.put((rank, raised, sorted(preds)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_range_fallback_is_agreed_on_by_all_ranks_before_the_gather():
+    """Rank 1's encoder leaves the fp16 range, rank 0's does not: both must raise RangeFallback (a rank that restarted alone
+    would leave its peer waiting in the all-gather, and the table would mix operand modes), and the repeated run completes."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() * 11) % 2000
+    procs = [ctx.Process(target=_range_worker, args=(r, 2, 7, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, list(range(7))), (1, True, list(range(7)))]
+
+
+def test_range_error_without_a_process_group_raises_rangefallback_and_other_errors_pass_through():
+    from molnextr_amd.engine import MnxError
+    with pytest.raises(E.RangeFallback):
+        E.run_inference(_RangeEngine("fp16x3", fail=True), _page, 5, batch_size=2)
+
+    class _Cap(_FakeEngine):
+        dtype = "fp16x3"
+
+        def predict(self, x, ref_batch=32, max_len=None):
+            raise MnxError("capacity", code=-5)
+    with pytest.raises(MnxError, match="capacity"):
+        E.run_inference(_Cap(), _page, 5, batch_size=2)

@@ -67,3 +67,26 @@ def test_other_errors_and_ranges_without_a_fallback_propagate(monkeypatch):
     with pytest.raises(MnxError):
         m._with_fallback(lambda e: (_ for _ in ()).throw(MnxError("range", code=MNX_ERR_RANGE)))
     assert len(_StubEngine.built) == 1
+
+
+def test_a_fallback_after_the_first_group_restarts_the_whole_call(monkeypatch):
+    """One predict_images call, one operand mode: when group 2 of 3 trips the range flag, the engine is rebuilt in bf16x3 and
+    ALL groups are computed again with it (the groups already done in fp16x3 are not kept)."""
+    m = _facade(monkeypatch)
+    m.group_images, m.tokenizer, m.device_preprocess = 2, None, False
+    seen = []
+
+    def fake_pipeline(eng, x, tok, ref_batch_size=16):
+        seen.append((eng.dtype, list(x)))
+        if eng.dtype == "fp16x3" and 2 in x:
+            raise MnxError("mnx_predict failed (-6)", code=MNX_ERR_RANGE)
+        return [{"id": i, "dtype": eng.dtype} for i in x]
+
+    monkeypatch.setattr(M, "predict_pipeline", fake_pipeline)
+    monkeypatch.setattr(M.molnextr, "_prefetched", lambda self, groups: iter(groups))
+    monkeypatch.setattr(M.molnextr, "_assemble", lambda self, preds, imgs, a, c: preds)
+    with pytest.warns(RuntimeWarning, match="bf16x3"):
+        out = m.predict_images([0, 1, 2, 3, 4], batch_size=2)
+    assert [p["id"] for p in out] == [0, 1, 2, 3, 4] and {p["dtype"] for p in out} == {"bf16x3"}
+    assert seen == [("fp16x3", [0, 1]), ("fp16x3", [2, 3]), ("bf16x3", [0, 1]), ("bf16x3", [2, 3]), ("bf16x3", [4])]
+    assert m._groups_done == 0

@@ -384,6 +384,37 @@ def test_fused_and_unfused_ticks_mix_in_one_job(eng, dev, synth_ckpt):
         _same_predictions(res[0], r)
 
 
+def test_persistent_encoder_grids_on_fewer_cus_give_identical_predictions(eng, dev, synth_ckpt):
+    """MNX_ENC_CUS=n launches the encoder's persistent kernels (gemm256x3_kernel, window_attn_pipe_kernel) on n (2 n)
+    workgroups so that 256 - n CUs stay free for the decode stream. Which workgroup computes a tile, and how a
+    layer's rows are split between the 256x256 and the 128x128 kernel, changes with n; the results must not (every GEMM kernel
+    adds an element's terms in one order). The setting is process-wide: restored to 256 at the end."""
+    from molnextr_amd.engine import Engine
+    imgs = W.synthetic_images(96, first_index=900).to(dev)
+    want = {k: v.cpu() for k, v in eng.predict(imgs, ref_batch=32).items()}
+    fwant = eng.encode(imgs[:32].contiguous()).cpu()
+    old = os.environ.get("MNX_ENC_CUS")
+    try:
+        for n in (224, 192):
+            os.environ["MNX_ENC_CUS"] = str(n)
+            e = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=96, dec_slots=128)
+            try:
+                assert torch.equal(e.encode(imgs[:32].contiguous()).cpu(), fwant), f"features differ bitwise at {n} workgroups"
+                _same_predictions(want, {k: v.cpu() for k, v in e.predict(imgs, ref_batch=32).items()})
+            finally:
+                e.close()
+        with pytest.raises(Exception, match="MNX_ENC_CUS"):
+            os.environ["MNX_ENC_CUS"] = "32"
+            Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=64)
+    finally:
+        os.environ["MNX_ENC_CUS"] = "256"
+        Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=64).close()
+        if old is None:
+            os.environ.pop("MNX_ENC_CUS", None)
+        else:
+            os.environ["MNX_ENC_CUS"] = old
+
+
 @pytest.mark.parametrize("B,beam,n_best,max_len", [(4, 3, 2, 160), (3, 5, 5, 96), (2, 8, 1, 64), (5, 2, 2, 480),
                                                    (8, 5, 2, 128),      # 40 rows: two 32-row tiles
                                                    (32, 5, 1, 96),      # BASELINE config 5: beam 5 x batch 32 = 5 tiles

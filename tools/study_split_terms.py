@@ -164,15 +164,39 @@ def encoder(img, sd, S, cfg=SWIN_B_384):
     return OS._ln(x, sd, "transformer.norm")
 
 
+def round_sig(x, bits, fp16_range=False):
+    """x rounded to `bits` significant bits (round to nearest even on the fp32 encoding): what a K / V cache entry stored in
+    fewer bytes keeps. bits = 8: bf16; 11: fp16 (fp16_range: per (layer, head) power-of-two scale into [2^14, 2^15), fp16
+    subnormals below 2^-24 of that); 16: bf16 hi + 8-bit lo (3 bytes); 19: fp16 hi + 8-bit lo (3 bytes)."""
+    if bits >= 24:
+        return x
+    xi = x.contiguous().view(torch.int32)
+    drop = 24 - bits
+    half = (1 << (drop - 1)) - 1
+    r = (xi + half + ((xi >> drop) & 1)) & ~((1 << drop) - 1)
+    y = r.view(torch.float32)
+    if fp16_range:          # scaled fp16: magnitudes below 2^-24 x (power-of-two scale of the tensor) lose bits / flush
+        amax = float(x.abs().max())
+        if amax > 0:
+            k = 15 - math.frexp(amax)[1]
+            q = math.ldexp(1.0, -24 - k)         # the scaled format's subnormal quantum, in x's units
+            small = x.abs() < math.ldexp(1.0, -14 - k)
+            y = torch.where(small, torch.round(x / q) * q, y)
+    return y
+
+
 @torch.no_grad()
-def forced_decode(features, sd, ids, lens, cfg=DECODER_DEFAULT):
+def forced_decode(features, sd, ids, lens, cfg=DECODER_DEFAULT, kv=None):
     """oracle.decoder.greedy_decode's loop, teacher-forced along `ids` (rows stop at `lens`): per (row, step) the masked
-    log-prob of the forced id and whether the argmax differs from it."""
+    log-prob of the forced id and whether the argmax differs from it. kv: optional rounding applied to every self- and
+    memory-K/V entry as it is stored (the K / V cache byte study; per (layer, head) tensors)."""
     P = OD.P
     memory = OD.enc_transform(features, sd)
     B, S_, D = memory.shape
     h, dh, L = cfg.heads, cfg.d_model // cfg.heads, cfg.layers
     mem_kv = OD.cross_kv(memory, sd, cfg)
+    if kv is not None:      # [B, h, S, dh] per layer: rounded per head
+        mem_kv = [tuple(torch.stack([kv(t[:, hh]) for hh in range(h)], 1) for t in pair) for pair in mem_kv]
     emb_w = sd[P + "embeddings.make_embedding.emb_luts.0.weight"]
     pe = sd[P + "embeddings.make_embedding.pe.pe"].reshape(-1, D)
     T = int(lens.max())
@@ -190,8 +214,13 @@ def forced_decode(features, sd, ids, lens, cfg=DECODER_DEFAULT):
         for l in range(L):
             lp = f"{P}decoder.transformer_layers.{l}"
             xn = OD._ln(x, sd, lp + ".layer_norm_1")
-            self_k[l, idx, :, step] = OD._lin(xn, sd, lp + ".self_attn.linear_keys").reshape(n, h, dh)
-            self_v[l, idx, :, step] = OD._lin(xn, sd, lp + ".self_attn.linear_values").reshape(n, h, dh)
+            k_new = OD._lin(xn, sd, lp + ".self_attn.linear_keys").reshape(n, h, dh)
+            v_new = OD._lin(xn, sd, lp + ".self_attn.linear_values").reshape(n, h, dh)
+            if kv is not None:
+                k_new = torch.stack([kv(k_new[:, hh]) for hh in range(h)], 1)
+                v_new = torch.stack([kv(v_new[:, hh]) for hh in range(h)], 1)
+            self_k[l, idx, :, step] = k_new
+            self_v[l, idx, :, step] = v_new
             q = OD._lin(xn, sd, lp + ".self_attn.linear_query")
             a = OD._mha(q, self_k[l, idx, :, :step + 1], self_v[l, idx, :, :step + 1], sd, lp + ".self_attn", cfg)
             query = a + x
@@ -228,6 +257,9 @@ def main():
     ap.add_argument("--ckpt", default="0", help="0: synthetic_checkpoint(0) against tests/golden/pixels_e2e; stress: "
                                                 "synthetic_checkpoint(1, stress=True) against tests/golden/pixels_stress")
     ap.add_argument("--ranges", action="store_true", help="print max |operand| per op class (fp16 range check)")
+    ap.add_argument("--kv", default=None,
+                    help="K / V cache byte study instead of the operand schemes: comma list of bf16,fp16,bf16+8,fp16+8 — the decoder "
+                         "runs teacher-forced on the fp32 features with every cached key / value rounded to that format")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     torch.set_num_threads(int(os.environ.get("STUDY_THREADS", "8")))
@@ -257,6 +289,23 @@ def main():
     print(f"fp32 features through the forced decoder: log-prob vs golden max {np.abs(lp_ref - g_lp)[m].max():.2e}, flips "
           f"{int(fl_ref[m].sum())} / {steps}", flush=True)
     rows = []
+    if args.kv:
+        fmt = {"bf16": (8, False, 2), "fp16": (11, True, 2), "bf16+8": (16, False, 3), "fp16+8": (19, True, 3), "fp32": (24, False, 4)}
+        for name in args.kv.split(","):
+            bits, rng, nbytes = fmt[name]
+            t0 = time.time()
+            lp, fl = forced_decode(ref, ck["decoder"], ids, lens, kv=lambda t: round_sig(t, bits, rng))
+            fm = [float(margin[b, t]) for b, t in zip(*np.nonzero(fl & m))]
+            rec = {"kv_format": name, "bytes_per_element": nbytes, "significant_bits": bits, "images": N,
+                   "logp_max_err": float(np.abs(lp - lp_ref)[m].max()), "logp_rms_err": float(np.sqrt((((lp - lp_ref)[m]) ** 2).mean())),
+                   "flips": int((fl & m).sum()), "steps": steps, "flip_margins": [round(x, 6) for x in fm[:20]],
+                   "seconds": round(time.time() - t0)}
+            rows.append(rec)
+            print(json.dumps(rec), flush=True)
+        if args.out:
+            with open(args.out, "w") as fo:
+                json.dump({"checkpoint": args.ckpt, "case": case, "study": "K/V cache bytes", "rows": rows}, fo, indent=1)
+        return
     for name in args.schemes.split(","):
         t0 = time.time()
         S = Scheme(name)

@@ -7,8 +7,8 @@ For every row count R the engine decodes R synthetic images for exactly T1 and f
 job each: encode once, then R alive rows in every tick); (time(T2) - time(T1)) / (T2 - T1) is the tick at R rows and key
 positions T1..T2 — encoder, admission and retirement cancel. Forms are selected through the engine's knobs:
 unfused = MNX_DEC_TILE=0 (decoder.hip, 8 launches per layer), fused = MNX_DEC_FUSED_MAX=4096 (dec_fused.hip, 3 launches),
-mid = MNX_DEC_FUSED_MAX=16 MNX_DEC_MID_MAX=4096 (dec_ma + dec_mb + dec_fb + dec_fc, 4 launches). Prints one table and, with
-every form, whether the three forms produced the same tokens."""
+mid = MNX_DEC_FUSED_MAX=16 MNX_DEC_MID_MAX=4096 (dec_ma + dec_mb + dec_fb + dec_fc, 4 launches). Prints one table and, when
+both were run, whether the fused and the mid form produced the same tokens (they are bit-identical by construction)."""
 import os
 import sys
 import time
@@ -55,10 +55,13 @@ def main():
         finally:
             eng.close()
     print(f"tick wall time, us (key positions {T1}..{T2}, every row alive); rows = rows of capacity")
-    print("rows  " + "".join(f"{f:>10s}" for f in forms) + ("   same tokens" if len(forms) > 1 else ""))
+    # fused and mid evaluate the same chains on the same numbers: their tokens must agree even over 200 free-running steps
+    # past EOS; the eight-launch form adds in another order (1e-5 apart) and may leave them at a near-tie of such a run
+    both = "fused" in forms and "mid" in forms
+    print("rows  " + "".join(f"{f:>10s}" for f in forms) + ("   fused == mid tokens" if both else ""))
     for R in rows_list:
-        same = all(torch.equal(toks[(forms[0], R)], toks[(f, R)]) for f in forms[1:])
-        print(f"{R:5d} " + "".join(f"{res[(f, R)]:10.1f}" for f in forms) + (f"   {same}" if len(forms) > 1 else ""))
+        same = both and torch.equal(toks[("fused", R)], toks[("mid", R)])
+        print(f"{R:5d} " + "".join(f"{res[(f, R)]:10.1f}" for f in forms) + (f"   {same}" if both else ""))
 
 
 if __name__ == "__main__":
