@@ -203,18 +203,19 @@ def cpu_baseline(ck, budget_s=85.0):
             "host": host, "thread_sweep": sweep, "runs": rows}
 
 
+GEMM_SOURCES = ("gemm.hip", "gemm256.hip", "gemm_res.hip", "common.h", "kernels.h")
+
+
 def library_sha16():
-    """First 16 hex digits of the sha256 over the kernel sources (molnextr_amd/csrc/*.hip, *.h, the public header) the loaded
-    library is built from: a measurement file made with other kernels is not evidence about these. (The sources rather than
-    the .so: two builds of the same sources need not be byte-identical. tools/collect_traffic.py computes the same digest.)"""
-    import glob
+    """First 16 hex digits of the sha256 over the sources of the encoder GEMM kernels and their dispatch (molnextr_amd/csrc:
+    GEMM_SOURCES) the loaded library is built from: a traffic file made with other GEMM kernels is not evidence about these.
+    (The sources rather than the .so: two builds of the same sources need not be byte-identical. tools/collect_traffic.py
+    computes the same digest.)"""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "molnextr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "molnextr_amd", "csrc", "*.h"))
-                   + [os.path.join(ROOT, "include", "molnextr_hip.h")])
-    for path in files:
-        h.update(os.path.basename(path).encode())
-        with open(path, "rb") as f:
+    for name in GEMM_SOURCES:
+        h.update(name.encode())
+        with open(os.path.join(ROOT, "molnextr_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 

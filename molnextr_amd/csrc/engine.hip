@@ -1340,7 +1340,7 @@ int mnx_probe_mfma(mnx_engine* h, int32_t ms_target, double* tflops, double* mhz
     HIPCHK(h, hipSetDevice(h->device));
     // 8 MFMAs of 16 cycles per iteration and wave, two waves per SIMD: ~256 cycles per iteration at ~1.9 GHz
     const int iters = (int)((double)ms_target * 1e-3 * 1.9e9 / 256.0);
-    HIPCHK(h, mfma_probe(iters, (float*)h->enc_flag, (hipStream_t)stream, tflops, mhz));
+    HIPCHK(h, mfma_probe(iters, (hipStream_t)stream, tflops, mhz));
     return MNX_OK;
 }
 

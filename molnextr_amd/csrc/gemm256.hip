@@ -923,11 +923,14 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(float* out, int iters) 
 }
 }  // namespace
 
-hipError_t mfma_probe(int iters, float* scratch, hipStream_t s, double* tflops, double* mhz) {
-    hipEvent_t e0, e1;
-    hipError_t e = hipEventCreate(&e0);
+hipError_t mfma_probe(int iters, hipStream_t s, double* tflops, double* mhz) {
+    float* scratch = nullptr;        // the kernel's never-taken store needs an address of its own (measurement path: not timed)
+    hipError_t e = hipMalloc((void**)&scratch, sizeof(float));
     if (e != hipSuccess) return e;
-    if ((e = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return e; }
+    hipEvent_t e0, e1;
+    e = hipEventCreate(&e0);
+    if (e != hipSuccess) { (void)hipFree(scratch); return e; }
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipFree(scratch); return e; }
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(512), 0, s, scratch, iters / 8 + 1);    // power management settles
     e = hipEventRecord(e0, s);
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(512), 0, s, scratch, iters);
@@ -938,6 +941,7 @@ hipError_t mfma_probe(int iters, float* scratch, hipStream_t s, double* tflops, 
     unsigned long long clk[2] = {0, 0};
     if (e == hipSuccess) e = hipMemcpyFromSymbol(clk, HIP_SYMBOL(mfma_probe_clk), sizeof(clk));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
     if (e != hipSuccess) return e;
     *tflops = 256.0 * 8.0 * (double)iters * 8.0 * (16.0 * 16.0 * 32.0 * 2.0) / ((double)ms * 1e-3) * 1e-12;
     *mhz = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0;

@@ -54,7 +54,7 @@ int persistent_cus();
 // measurement aids (gemm256.hip): shader clock of the gemm256x3_kernel launches since the last reset; sustained rate of a
 // register-only fp16 MFMA loop on random operands (every CU, `iters` x 8 instructions per wave)
 hipError_t x3_clock_read(double* mhz, bool reset);
-hipError_t mfma_probe(int iters, float* scratch, hipStream_t s, double* tflops, double* mhz);
+hipError_t mfma_probe(int iters, hipStream_t s, double* tflops, double* mhz);
 hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                             const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp);
 

@@ -184,5 +184,5 @@ def test_traffic_figure_is_only_taken_from_a_file_made_with_these_kernel_sources
     # the collector computes the digest the same way (it is a script: run its digest lines on this tree)
     src = open(os.path.join(ROOT, "tools", "collect_traffic.py")).read()
     ns = {"__file__": os.path.join(ROOT, "tools", "collect_traffic.py"), "out": {}}
-    exec(src[src.index("# the kernel sources the counters were collected on"):src.index("json.dump(out, open(sys.argv[3]")], ns)
+    exec(src[src.index("# the GEMM kernel sources the counters were collected on"):src.index("json.dump(out, open(sys.argv[3]")], ns)
     assert ns["out"]["library_sha16"] == have

@@ -34,17 +34,15 @@ out = {"kernel": f"mnx::gemm_tn_* / gemm256* / gemm_res kernels (all encoder GEM
        "read_bytes_per_launch": 2 * tot_f * 1024 / n_f, "write_bytes_per_launch": tot_w * 1024 / n_w,
        "hbm_bytes_per_launch": (2 * tot_f / n_f + tot_w / n_w) * 1024,
        "note": "FETCH_SIZE doubled (gfx950 undercount, calibrated); Infinity-Cache hits are counted as traffic"}
-# the kernel sources the counters were collected on (bench.py::library_sha16 computes the same digest and refuses the file
-# when its own differs)
-import glob
+# the GEMM kernel sources the counters were collected on (bench.py::library_sha16 computes the same digest over the same files
+# and refuses the file when its own differs)
 import hashlib
 import os
 _root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 _h = hashlib.sha256()
-for _p in sorted(glob.glob(os.path.join(_root, "molnextr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(_root, "molnextr_amd", "csrc", "*.h"))
-                 + [os.path.join(_root, "include", "molnextr_hip.h")]):
-    _h.update(os.path.basename(_p).encode())
-    with open(_p, "rb") as _f:
+for _name in ("gemm.hip", "gemm256.hip", "gemm_res.hip", "common.h", "kernels.h"):
+    _h.update(_name.encode())
+    with open(os.path.join(_root, "molnextr_amd", "csrc", _name), "rb") as _f:
         _h.update(_f.read())
 out["library_sha16"] = _h.hexdigest()[:16]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
