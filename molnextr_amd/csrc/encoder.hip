@@ -445,6 +445,16 @@ __global__ __launch_bounds__(576) void window_attn_kernel(const T* __restrict__ 
 // O = vh.ph + vh.pl + vl.ph on the same MFMAs (small terms first), the context leaves as hi / lo planes. The
 // un-normalised probabilities are scaled by 2^10 before they are split (exp(s - max) <= 1 would put most lo parts into the
 // fp16 subnormal range); the scale cancels in O / sum. Same structure and index arithmetic as window_attn_kernel.
+// Softmax of the split-operand window attention in the log2 domain (round 5): the score is formed as acc * (scale * log2 e) +
+// bias * log2 e (the bias column is multiplied once when it is staged in LDS), the shift mask is -100 log2 e, and a probability is
+// v_exp_f32(score - (max - 10)) — the 2^10 that keeps the lo plane of P out of the fp16 subnormals folded into the exponent —
+// instead of v_exp_f32((score - max) * log2 e) * 1024: two VALU operations per score fewer (72 of ~625 per item and lane). Both
+// split kernels use the same form (their outputs stay bit-identical to each other).
+#ifndef MNX_ATTN_EXP2
+#define MNX_ATTN_EXP2 1
+#endif
+constexpr float ATTN_LOG2E = 1.4426950408889634f;
+
 template <typename T>
 __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restrict__ qkv, size_t qkv_lo,
                                                                 const float* __restrict__ table, T* __restrict__ out,
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
         const int reg = (last_y ? (ty < WS - shift ? 1 : 2) : 0) * 3 + (last_x ? (tx < WS - shift ? 1 : 2) : 0);
         kinfo[t] = (ty * (2 * WS - 1) + tx) | (reg << 16);
     }
-    for (int i = tid; i < 529; i += NTHR) tab[i] = table[i * heads + head];
+    for (int i = tid; i < 529; i += NTHR) tab[i] = table[i * heads + head] * (MNX_ATTN_EXP2 ? ATTN_LOG2E : 1.0f);
     for (int i = tid; i < 2 * HD * (VT_STRIDE - WN); i += NTHR) {
         const int pl = i / (HD * (VT_STRIDE - WN)), j = i % (HD * (VT_STRIDE - WN));
         Vt[pl][(j / (VT_STRIDE - WN)) * VT_STRIDE + WN + j % (VT_STRIDE - WN)] = (T)0.f;
@@ -518,7 +528,8 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
         acc[kt] = H16<T>::mfma(kh, qh, a);
     }
 
-    const float scale = 0.17677669529663687f;
+    const float scale = 0.17677669529663687f * (MNX_ATTN_EXP2 ? ATTN_LOG2E : 1.0f);
+    const float maskv = -100.0f * (MNX_ATTN_EXP2 ? ATTN_LOG2E : 1.0f);
     MNX_ATTN_STAMP(4);
     const int qinfo = kinfo[wave * 16 + fr];
     const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS);
@@ -531,19 +542,20 @@ __global__ __launch_bounds__(576) void window_attn_split_kernel(const T* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float sc = acc[kt][r] * scale + tab[qa - (kis[r] & 0xffff)];
-            if ((kis[r] >> 16) != rq) sc += -100.0f;
+            if ((kis[r] >> 16) != rq) sc += maskv;
             acc[kt][r] = sc;
             mx = fmaxf(mx, sc);
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxm = mx - 10.0f;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 9; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float pv = __expf(acc[kt][r] - mx) * 1024.0f;
+            const float pv = MNX_ATTN_EXP2 ? __builtin_amdgcn_exp2f(acc[kt][r] - mxm) : __expf(acc[kt][r] - mx) * 1024.0f;
             acc[kt][r] = pv;
             sum += pv;
         }
@@ -742,7 +754,7 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
         const int* kinfo = kinfo4 + var_n * WN;
         float* tabc = tab + cur * WA_TABN;
         const int tid = thread_id(), fr = tid & 15, fg = (tid >> 4) & 3;
-        if (tid < 529) tabc[tid] = tab_n;
+        if (tid < 529) tabc[tid] = tab_n * (MNX_ATTN_EXP2 ? ATTN_LOG2E : 1.0f);
         __syncthreads();                                      // every wave's DMA landed; buffer cur^1 is free (item it-1 is done)
         const bool more = it + 1 < it1;
         if (more) {
@@ -774,7 +786,8 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
         // bias index = (qy-ky+11)*23 + (qx-kx+11) = (qy*23+qx + 11*24) - (ky*23+kx). A lane's four keys of a tile
         // (16 kt + 4 fg + r) are consecutive tokens of one window row (12 % 4 == 0), so their four bias values are
         // CONSECUTIVE table entries, descending: one index per tile, two paired LDS reads instead of four gathers.
-        const float scale = 0.17677669529663687f;
+        const float scale = 0.17677669529663687f * (MNX_ATTN_EXP2 ? ATTN_LOG2E : 1.0f);
+        const float maskv = -100.0f * (MNX_ATTN_EXP2 ? ATTN_LOG2E : 1.0f);
         const int qinfo = kinfo[wave * 16 + fr];
         const int qa = (qinfo & 0xffff) + (WS - 1) * (2 * WS) - 3;
         const int rq = qinfo >> 16;
@@ -792,19 +805,20 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float sc = acc[kt][r] * scale + tp[3 - r];
-                if (MASKED && (kis[r] >> 16) != rq) sc += -100.0f;
+                if (MASKED && (kis[r] >> 16) != rq) sc += maskv;
                 acc[kt][r] = sc;
                 mx = fmaxf(mx, sc);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxm = mx - 10.0f;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 9; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(acc[kt][r] - mx) * 1024.0f;
+                const float pv = MNX_ATTN_EXP2 ? __builtin_amdgcn_exp2f(acc[kt][r] - mxm) : __expf(acc[kt][r] - mx) * 1024.0f;
                 acc[kt][r] = pv;
                 sum += pv;
             }
