@@ -11,81 +11,169 @@ namespace mnx {
 
 // =============================================================================================
 // K1  patch embedding: Conv2d(3, C, k=4, s=4) + bias -> LayerNorm(C)     (reference transformers.py:405-419)
-//     One workgroup = one patch row of one image (chunks of 32 patches, 8 threads per patch).
+//     One workgroup = one patch row of one image, 8 threads per patch position, NP patches per thread.
 // =============================================================================================
+// The [48][C] weight image (24 KiB at C = 128) and the row's 12 pixel lines are staged in LDS once per workgroup. Thread
+// (p = tid >> 3, part = tid & 7) owns CPT = C/8 consecutive channels (<= 16) of the NP patches p, p + 32, ... of a chunk of
+// 32 NP patches: every weight quad read from LDS feeds NP patches. What the first form of this kernel (one patch per thread,
+// C a run-time argument; 0.18 of the HBM rate its 3.3 GB per 512 images need, profiles/r05_bench_steps20.json.log) lost, in the
+// order it was found in the ISA:
+//   * `if (j < cpt)` with a run-time cpt made every weight quad a branch of its own: ds_read, s_waitcnt lgkmcnt(0), a few
+//     FMAs, branch — each LDS round trip exposed. CPT is a template argument now: straight-line code, reads issued ahead.
+//   * the staging loops waited for every global load before its LDS store (one load in flight per thread, ten round trips per
+//     workgroup). All of a thread's quads are requested first, at clamped addresses (a predicated load is a branch).
+//   * one LDS float per FMA (now 20 quads per 192 FMAs), and at C = 128 the eight channel segments of a patch sit 64 B apart:
+//     parts p and p + 4 on the same banks in every ds_read_b128 lane group (MI355X_MICROARCH.md, LDS) — rows are C + 4 floats
+//     and the upper half of a row is stored 4 floats later.
+// Per output the arithmetic is what it was: bias, then the 48 taps in (channel, ky, kx) order, the LayerNorm sums over the
+// thread's channels and then over the 8 lanes of the patch. The variance and the affine step are explicit fmaf (sq = fma(d, d,
+// sq); fma(d * rstd, gamma, beta)): that is what the first form compiled to, and left to -ffp-contract the compiler vectorised
+// the three-patch form into separate multiplies and adds — the encoder output changed in its last bits (tools/features_hash.py
+// compares the two libraries: identical now).
+constexpr int PE_NP = 3;            // 96 patches per chunk: one chunk per row at 384 x 384
+template <int CPT>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w_t,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ x,
-                                                          int S, int C, int G) {
-    // One workgroup = one patch ROW of one image, walked in chunks of 32 patches: the [48][C] weight image (24 KiB at
-    // C = 128, more than the 16 KiB of tokens a chunk produces) is staged in LDS once per row, not once per chunk.
-    // 8 threads per patch, each owning CPT = C/8 consecutive channels (<= 16), so the LayerNorm reduction is 3
-    // cross-lane steps and every patch row is written as one contiguous C*4-byte run.
+                                                          int S, int G) {
+    constexpr int C = 8 * CPT;
+    constexpr int PW = 128 * PE_NP;             // pixels per staged line
+    constexpr int WS = C + 4;                   // weight row stride in LDS
+    constexpr bool SWZ = CPT == 16;             // parts 4..7 (channels 64..127) stored 4 floats later
+    constexpr int NWQ = (12 * C + 255) / 256;   // weight quads per thread
+    constexpr int NPQ = (12 * (PW / 4) + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* wt = sm;             // [48][C]
-    float* pix = sm + 48 * C;   // [3][4][128]
+    float* wt = sm;             // [48][WS]
+    float* pix = sm + 48 * WS;  // [3][4][PW]
     const int tid = threadIdx.x;
     const int py = blockIdx.x, b = blockIdx.y;
-    for (int i = tid; i < 48 * C; i += 256) wt[i] = w_t[i];
     const int p = tid >> 3, part = tid & 7;
-    const int cpt = C >> 3;                 // channels per thread: 4, 8, 12 or 16
-    const int c0 = part * cpt;
-    for (int px0 = 0; px0 < G; px0 += 32) {
-        if (px0 > 0) __syncthreads();       // the previous chunk's pixels have been consumed
-        for (int i = tid; i < 3 * 4 * 128; i += 256) {
-            int ci = i >> 9, ky = (i >> 7) & 3, xx = i & 127;
-            int gx = px0 * 4 + xx;
-            pix[i] = gx < S ? img[((size_t)(b * 3 + ci) * S + (py * 4 + ky)) * S + gx] : 0.f;
+    const int c0 = part * CPT;
+    f32x4 wq[NWQ];
+#pragma unroll
+    for (int k = 0; k < NWQ; ++k) wq[k] = ((const f32x4*)w_t)[min(tid + 256 * k, 12 * C - 1)];
+    for (int px0 = 0; px0 < G; px0 += 32 * PE_NP) {
+        f32x4 pq[NPQ];
+#pragma unroll
+        for (int k = 0; k < NPQ; ++k) {
+            const int i = min(tid + 256 * k, 12 * (PW / 4) - 1);
+            const int line = i / (PW / 4), xq = i % (PW / 4);       // line = ci * 4 + ky
+            const int gx = px0 * 4 + xq * 4;                        // S % 4 == 0: a quad is inside the image or outside it
+            pq[k] = *(const f32x4*)(img + ((size_t)(b * 3 + (line >> 2)) * S + (py * 4 + (line & 3))) * S + min(gx, S - 4));
+        }
+        f32x4 bq[CPT / 4];
+#pragma unroll
+        for (int j = 0; j < CPT / 4; ++j) bq[j] = *(const f32x4*)(bias + c0 + 4 * j);
+        __builtin_amdgcn_sched_barrier(0);      // keep the requests together, ahead of the first wait
+        if (px0 > 0) __syncthreads();           // the previous chunk's pixels have been consumed
+        else {
+#pragma unroll
+            for (int k = 0; k < NWQ; ++k) {
+                const int i = tid + 256 * k;
+                const int row = i / (C / 4), c = (i % (C / 4)) * 4;
+                if (i < 12 * C) *(f32x4*)(wt + row * WS + c + (SWZ ? (c >> 6) * 4 : 0)) = wq[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPQ; ++k) {
+            const int i = tid + 256 * k;
+            const int line = i / (PW / 4), xq = i % (PW / 4);
+            f32x4 v = pq[k];
+            if (px0 * 4 + xq * 4 >= S) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i < 12 * (PW / 4)) *(f32x4*)(pix + line * PW + xq * 4) = v;
         }
         __syncthreads();
-        const int px = px0 + p;
-        float acc[16];
+        float acc[PE_NP][CPT];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = j < cpt ? bias[c0 + j] : 0.f;
-#pragma unroll 4
-        for (int i = 0; i < 48; ++i) {
-            const float v = pix[((i >> 2) << 7) + p * 4 + (i & 3)];  // (ci*4+ky)*128 + p*4 + kx
-            const float* wr = wt + i * C + c0;
+        for (int j = 0; j < CPT; ++j)
 #pragma unroll
-            for (int j = 0; j < 16; j += 4)
-                if (j < cpt) {
-                    const f32x4 w4 = *(const f32x4*)(wr + j);
-                    acc[j] = fmaf(v, w4[0], acc[j]); acc[j + 1] = fmaf(v, w4[1], acc[j + 1]);
-                    acc[j + 2] = fmaf(v, w4[2], acc[j + 2]); acc[j + 3] = fmaf(v, w4[3], acc[j + 3]);
+            for (int q = 0; q < PE_NP; ++q) acc[q][j] = bq[j >> 2][j & 3];
+        // tap loop, software-pipelined by hand: the weight quads of tap t + 1 (and, at kx = 3, the next line's pixels) are
+        // requested before tap t's FMAs, the scheduling barrier keeps a tap's requests ahead of the previous tap's FMAs. (244
+        // registers at C = 128: two workgroups per CU, where the LDS would allow three — capped at 168 registers the compiler
+        // spills 70; two are enough to cover one workgroup's staging with the other's taps.)
+        const float* wbase = wt + c0 + (SWZ ? (part >> 2) * 4 : 0);
+        const float* pbase = pix + p * 4;
+        f32x4 wc[CPT / 4], pv[PE_NP];
+#pragma unroll
+        for (int j = 0; j < CPT / 4; ++j) wc[j] = *(const f32x4*)(wbase + 4 * j);
+#pragma unroll
+        for (int q = 0; q < PE_NP; ++q) pv[q] = *(const f32x4*)(pbase + q * 128);
+#pragma unroll 1
+        for (int line = 0; line < 12; ++line) {
+            f32x4 pn[PE_NP];
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                f32x4 wn[CPT / 4];
+                const float* wr = wbase + min(line * 4 + kx + 1, 47) * WS;
+#pragma unroll
+                for (int j = 0; j < CPT / 4; ++j) wn[j] = *(const f32x4*)(wr + 4 * j);
+                if (kx == 3) {
+                    const float* pr = pbase + min(line + 1, 11) * PW;
+#pragma unroll
+                    for (int q = 0; q < PE_NP; ++q) pn[q] = *(const f32x4*)(pr + q * 128);
                 }
+#pragma unroll
+                for (int j = 0; j < CPT; j += 4) {
+                    const f32x4 w4 = wc[j >> 2];
+#pragma unroll
+                    for (int q = 0; q < PE_NP; ++q) {
+                        const float v = pv[q][kx];
+                        acc[q][j] = fmaf(v, w4[0], acc[q][j]); acc[q][j + 1] = fmaf(v, w4[1], acc[q][j + 1]);
+                        acc[q][j + 2] = fmaf(v, w4[2], acc[q][j + 2]); acc[q][j + 3] = fmaf(v, w4[3], acc[q][j + 3]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < CPT / 4; ++j) wc[j] = wn[j];
+            }
+#pragma unroll
+            for (int q = 0; q < PE_NP; ++q) pv[q] = pn[q];
         }
-        float s = 0.f;
+        __builtin_amdgcn_sched_barrier(0);      // gamma / beta requested here, not above the tap loop (32 registers)
+        f32x4 g4[CPT / 4], b4[CPT / 4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s += j < cpt ? acc[j] : 0.f;
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        const float mean = s / (float)C;
-        float sq = 0.f;
+        for (int j = 0; j < CPT / 4; ++j) { g4[j] = *(const f32x4*)(gamma + c0 + 4 * j); b4[j] = *(const f32x4*)(beta + c0 + 4 * j); }
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (j < cpt) { acc[j] -= mean; sq += acc[j] * acc[j]; }
-        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-        const float rstd = rsqrtf(sq / (float)C + 1e-5f);
-        if (px < G) {
-            float* o = x + ((size_t)(b * G + py) * G + px) * C + c0;
+        for (int q = 0; q < PE_NP; ++q) {
+            const int px = px0 + q * 32 + p;
+            float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; j += 4)
-                if (j < cpt) {
-                    const f32x4 g4 = *(const f32x4*)(gamma + c0 + j), b4 = *(const f32x4*)(beta + c0 + j);
-                    f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
-                    *(f32x4*)(o + j) = v * rstd * g4 + b4;
+            for (int j = 0; j < CPT; ++j) s += acc[q][j];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            const float mean = s / (float)C;
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) { acc[q][j] -= mean; sq = fmaf(acc[q][j], acc[q][j], sq); }
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            const float rstd = rsqrtf(sq / (float)C + 1e-5f);
+            if (px < G) {
+                float* o = x + ((size_t)(b * G + py) * G + px) * C + c0;
+#pragma unroll
+                for (int j = 0; j < CPT; j += 4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[q][j + e] * rstd, g4[j >> 2][e], b4[j >> 2][e]);
+                    *(f32x4*)(o + j) = v;
                 }
+            }
         }
     }
 }
 
 hipError_t launch_patch_embed(const float* img, const float* w_t, const float* bias, const float* gamma,
                               const float* beta, float* x, int B, int S, int C, hipStream_t s) {
-    if (C > 128 || (S & 3)) return hipErrorInvalidValue;
+    if (C > 128 || (C & 31) || (S & 3) || S < 4) return hipErrorInvalidValue;
     const int G = S / 4;
     dim3 grid(G, B), block(256);
-    size_t smem = (size_t)(48 * C + 3 * 4 * 128) * sizeof(float);
-    hipLaunchKernelGGL(patch_embed_kernel, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, C, G);
+    size_t smem = (size_t)(48 * (C + 4) + 3 * 4 * 128 * PE_NP) * sizeof(float);
+    switch (C >> 3) {
+        case 4: hipLaunchKernelGGL(patch_embed_kernel<4>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
+        case 8: hipLaunchKernelGGL(patch_embed_kernel<8>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
+        case 12: hipLaunchKernelGGL(patch_embed_kernel<12>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
+        default: hipLaunchKernelGGL(patch_embed_kernel<16>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
+    }
     return hipGetLastError();
 }
 
