@@ -58,7 +58,7 @@ enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1, MNX_DTYPE_FP32 = 2, MNX_DTYPE_BF1
 /* Architecture + capacity. Defaults of the reference inference config are in the comments
  * (MolNexTR/models/transformers.py:547-551 swin_base; MolNexTR/model.py:50-81; MolNexTR/utils.py:25). */
 typedef struct {
-    int32_t img_size;        /* 384 */
+    int32_t img_size;        /* 384; every stage's grid a multiple of `window`, the last stage's grid <= 512 positions */
     int32_t patch;           /* 4   */
     int32_t embed_dim;       /* 128 */
     int32_t n_stages;        /* 4   */

@@ -243,6 +243,9 @@ int check_cfg(const mnx_config& c, std::string& why) {
             g /= 2;
         }
     }
+    // g x g is the memory the decoder attends over: dec_attn_kernel scores two keys per thread (<= 512), the fused ticks hold
+    // PS_CROSS = 160 (tick_tile falls back to the eight-launch tick above that); the reference's 384 x 384 gives 144
+    if (g * g > 512) return bad("the encoder's last grid must have <= 512 positions (the cross-attention kernels hold 512 keys)");
     if (c.dec_dim != 256 || c.dec_heads != 8) return bad("decoder kernels are built for d_model 256, 8 heads");
     if (c.dec_layers < 1 || c.dec_layers > MAX_DEC_LAYERS) return bad("dec_layers out of range");
     if (c.dec_ff % 256 || c.dec_ff < 256) return bad("dec_ff must be a multiple of 256");

@@ -48,6 +48,38 @@ def test_create_rejects_bad_arguments_without_gpu(lib):
     assert not h.value
 
 
+def _reference_config():
+    """include/molnextr_hip.h's mnx_config for the reference model (Swin-B 384, 6-layer decoder), as Engine fills it"""
+    cfg = engine.MnxConfig()
+    cfg.img_size, cfg.patch, cfg.embed_dim, cfg.n_stages, cfg.window = 384, 4, 128, 4, 12
+    for i, (d, h) in enumerate(zip((2, 2, 18, 2), (4, 8, 16, 32))):
+        cfg.depths[i], cfg.heads[i] = d, h
+    cfg.dec_layers, cfg.dec_dim, cfg.dec_heads, cfg.dec_ff = 6, 256, 8, 1024
+    cfg.vocab, cfg.sym_offset, cfg.coord_bins, cfg.pe_len = 256, 128, 64, 5000
+    cfg.max_len, cfg.max_batch, cfg.max_atoms, cfg.compute_dtype, cfg.dec_slots = 480, 32, 160, engine.DTYPES["fp16x3"], 2048
+    return cfg
+
+
+def test_create_validates_the_memory_grid_before_touching_a_device(lib):
+    """The cross-attention kernels hold <= 512 memory positions (two keys per thread): a config whose last encoder grid is
+    larger (768 x 768 pixels: 24 x 24 = 576) must be refused by mnx_create, not decoded with the keys beyond 512 dropped."""
+    import torch
+    h = ctypes.c_void_p()
+    desc = (engine.MnxWeightDesc * 1)()
+    cfg = _reference_config()
+    rc = lib.mnx_create(ctypes.byref(cfg), desc, 1, 0, ctypes.byref(h))
+    if not torch.cuda.is_available():       # the reference config passes the config check: the next refusal is the device
+        assert rc != 0 and b"no HIP device" in lib.mnx_last_error(None)
+    elif rc == 0:
+        lib.mnx_destroy(h)
+    cfg.img_size = 768
+    h = ctypes.c_void_p()
+    assert lib.mnx_create(ctypes.byref(cfg), desc, 1, 0, ctypes.byref(h)) == -1
+    msg = lib.mnx_last_error(None)
+    assert b"bad config" in msg and b"512" in msg, msg
+    assert not h.value
+
+
 def test_engine_refuses_to_run_without_gpu():
     """No CPU fallback: constructing an Engine on a box without an MI355X must raise."""
     import torch
