@@ -35,14 +35,17 @@ __global__ __launch_bounds__(256) void sgemm_tn_kernel(const float* __restrict__
     const float* ap = A + (size_t)min(m0 + lr, M - 1) * K + lk;
     const float* wp = W + (size_t)min(n0 + lr, N - 1) * K + lk;
     float acc[4][4] = {};
+    f32x4 a = *(const f32x4*)ap, w = *(const f32x4*)wp;
     for (int k0 = 0; k0 < K; k0 += 16) {
-        const f32x4 a = *(const f32x4*)(ap + k0), w = *(const f32x4*)(wp + k0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             As[lk + j][lr] = a[j];
             Ws[lk + j][lr] = w[j];
         }
         __syncthreads();
+        const int kn = k0 + 16 < K ? k0 + 16 : k0;       // the next slice travels under this slice's 256 FMAs
+        a = *(const f32x4*)(ap + kn);
+        w = *(const f32x4*)(wp + kn);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const f32x4 av = *(const f32x4*)&As[k][ty * 4], wv = *(const f32x4*)&Ws[k][tx * 4];
@@ -317,6 +320,25 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     const long long rowb = a.cross ? (long long)a.st->row_mem[row] : (long long)slot;
     const float* Kb = a.K + rowb * a.row_stride + hd * a.head_stride;
     const float* Vb = a.V + rowb * a.row_stride + hd * a.head_stride;
+    // P.V: wave w takes keys w*8 + kg + 32*i (kg = lane>>3), channel quad dq = lane&7: 32 keys per block-load. The first
+    // VPRE block-loads (160 keys: all of the memory's 144, most self-attention rows) are requested HERE, before the keys: V does
+    // not depend on the scores, and after the softmax the loop below paid two more dependent round trips (its unrolled body, then
+    // its remainder) in a kernel that is five round trips long at the row counts where it is latency-bound (192-256 rows: one
+    // round of workgroups). Same operations in the same order: bit-identical.
+    constexpr int VPRE = 5;
+    const int kg = lane >> 3, dq = lane & 7;
+    const int nk32 = (nkeys + 31) & ~31;
+    f32x4 vpre[VPRE];
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i) {
+        const int key = wave * 8 + kg + 32 * i;
+        const int kk = key < nkeys ? key : nkeys - 1;
+        const float* vp = Vb + (size_t)kk * a.kstride;
+        if (ANC)
+            vp = a.V + (long long)a.anc[(size_t)slot * a.anc_stride + kk] * a.row_stride + hd * a.head_stride +
+                 (size_t)kk * a.kstride;
+        vpre[i] = *(const f32x4*)(vp + dq * 4);
+    }
     f32x4 q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + (size_t)row * 256 + hd * 32 + i * 4);
@@ -361,19 +383,25 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
-    // P.V: wave w takes keys w*8 + kg + 32*i (kg = lane>>3), channel quad dq = lane&7: 32 keys per block-load
-    const int kg = lane >> 3, dq = lane & 7;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    const int nk32 = (nkeys + 31) & ~31;
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i)
+        if (32 * i < nk32) {        // uniform: key = 32 i + (< 32)
+            const float p = ps[wave * 8 + kg + 32 * i];     // 0 for key >= nkeys
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(vpre[i][e], p, o[e]);
+        }
 #pragma unroll 4
-    for (int key = wave * 8 + kg; key < nk32; key += 32) {
+    for (int key = wave * 8 + kg + 32 * VPRE; key < nk32; key += 32) {
         const int kk = key < nkeys ? key : nkeys - 1;
         const float* vp = Vb + (size_t)kk * a.kstride;
         if (ANC)
             vp = a.V + (long long)a.anc[(size_t)slot * a.anc_stride + kk] * a.row_stride + hd * a.head_stride +
                  (size_t)kk * a.kstride;
         const f32x4 v = *(const f32x4*)(vp + dq * 4);
-        o += v * ps[key];       // ps[key] == 0 for key >= nkeys
+        const float p = ps[key];        // 0 for key >= nkeys
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], p, o[e]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
