@@ -213,6 +213,73 @@ def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fe
         assert len(re.findall(r"ds_read_b64_tr_b16", body)) == 36, name
 
 
+def test_patch_embed_isa_requests_its_staging_loads_together_and_has_a_branch_free_tap_loop(tmp_path):
+    """patch_embed_kernel<CPT> (encoder.hip) was 0.18 of its HBM bound while the channel count was a run-time argument: every
+    weight quad sat in a branch of its own (LDS read, wait, 4 FMAs), and the staging loops waited for each global load before
+    storing it to LDS. What the rewrite rests on, in the ISA of the C = 128 instantiation: (1) no scratch in any
+    instantiation; (2) all of a thread's staging loads (6 weight quads, 5 pixel quads, bias) are issued before the first wait
+    for vector memory; (3) between the second barrier (tiles staged) and the first store there are the tap loop's back edge
+    and the `px < G` guard, no other branch, no wait for vector memory other than the one for the hoisted gamma / beta, and
+    one line's worth of packed FMAs (4 taps x 16 channels x 3 patches / 2 = 96)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "molnextr_amd", "csrc", "encoder.hip")
+    out = tmp_path / "encoder.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    kernels = dict(re.findall(r"^(_ZN3mnx18patch_embed_kernelILi\d+E\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M))
+    assert len(kernels) == 4                                   # C = 32, 64, 96, 128
+    for name, body in kernels.items():
+        assert "scratch_" not in body, name
+    body = next(b for n, b in kernels.items() if "ILi16E" in n)
+    first_wait = re.search(r"s_waitcnt vmcnt", body).start()
+    assert len(re.findall(r"global_load_dwordx4", body[:first_wait])) >= 6 + 5 + 4
+    barriers = [m.start() for m in re.finditer(r"s_barrier", body)]
+    assert len(barriers) == 2
+    taps = body[barriers[1]:body.index("global_store_dwordx4")]
+    assert len(re.findall(r"s_cbranch", taps)) == 2, re.findall(r"s_cbranch\w*", taps)
+    assert len(re.findall(r"s_waitcnt vmcnt", taps)) <= 1
+    assert len(re.findall(r"v_pk_fma_f32", taps)) >= 96
+    assert len(re.findall(r"ds_read_b128", taps)) >= 4 * 4 + 3          # a line: 4 taps x 4 weight quads, 3 pixel quads
+
+
+def test_dec_attn_isa_has_its_value_rows_in_flight_before_it_waits_for_a_key(tmp_path):
+    """dec_attn_kernel (decoder.hip): the first five value block-loads are requested ahead of the keys, so that the kernel's
+    first wait for vector memory has 5 value quads + 8 key quads outstanding (before: the values were fetched after the
+    softmax, two more dependent round trips); sgemm_tn_kernel: the next K slice's two loads sit between the two barriers of
+    the current slice (under its FMAs), not in front of the LDS stores."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "molnextr_amd", "csrc", "decoder.hip")
+    out = tmp_path / "decoder.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    kernels = dict(re.findall(r"^(_ZN3mnx15dec_attn_kernelILb[01]E\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M))
+    assert len(kernels) == 2
+    for name, body in kernels.items():
+        assert "scratch_" not in body, name
+        first_wait = re.search(r"s_waitcnt vmcnt", body).start()
+        if "ILb1E" in name:     # beam search: the slot holding each key comes from the ancestry table (five entries first)
+            assert len(re.findall(r"global_load_dword ", body[:first_wait])) >= 5, name
+        else:
+            n = len(re.findall(r"global_load_dwordx4", body[:first_wait]))
+            assert n >= 13, (name, n)
+    sg = re.search(r"^_ZN3mnx15sgemm_tn_kernel\w+:[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M).group(1)
+    loop = sg[sg.index("s_barrier"):]
+    loop = loop[:loop.index("s_barrier", 10) + 9]              # first barrier .. second barrier of the K loop
+    assert len(re.findall(r"global_load_dwordx4", loop)) == 2 and "ds_write" not in loop
+
+
 def test_fused_decode_tick_isa_no_scratch_small_row_mfma_and_register_budget(tmp_path):
     """dec_fused.hip: the three kernels per decoder layer of the greedy tick. What its design rests on, checked in the ISA:
     (1) no scratch — the 1024-thread instantiations (4 rows per workgroup) have 128 registers per thread and every one of
