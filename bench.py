@@ -56,6 +56,7 @@ sys.path.insert(0, ROOT)
 
 from molnextr_amd import shard  # noqa: E402
 from molnextr_amd import weights as W  # noqa: E402
+from molnextr_amd.engine import DEFAULT_DTYPE, FP16X3M_TWO_TERM  # noqa: E402
 from molnextr_amd.tokenizer import get_tokenizer  # noqa: E402
 
 BATCH = 32
@@ -77,22 +78,57 @@ def run_batch(eng, images, kmax, max_len, beam=1):
     return tokens, lengths, atom_idx, n_atoms, edges
 
 
-def gemm_algorithmic_bytes(batch=BATCH, planes=1):
-    """Average algorithmic HBM bytes per encoder GEMM launch (A + W read once, output written once, residual read
-    for the two residual epilogues) for Swin-B @384: the figure `roofline.traffic` is compared with. planes = 2 for
-    the split modes (every 16-bit operand / output is a hi and a lo plane)."""
-    total, launches = 0, 0
+def encoder_gemm_layers(batch=BATCH):
+    """(stage, op class, M, N, K, launches) of every encoder Linear for Swin-B @384 (op classes as molnextr_amd.engine.SPLIT_CLASSES;
+    the patch-merging reduction behind stage s counts as stage s)."""
     for s, (L, C, depth) in enumerate([(9216, 128, 2), (2304, 256, 2), (576, 512, 18), (144, 1024, 2)]):
         M = batch * L
-        e16 = 2 * planes
-        per_block = [(M, 3 * C, C, e16, 0), (M, C, C, 4, 4), (M, 4 * C, C, e16, 0), (M, C, 4 * C, 4, 4)]
-        for (m, n, k, out_b, res_b) in per_block:
-            total += depth * (m * k * e16 + n * k * e16 + m * n * (out_b + res_b))
-            launches += depth
+        yield s, "qkv", M, 3 * C, C, depth
+        yield s, "proj", M, C, C, depth
+        yield s, "fc1", M, 4 * C, C, depth
+        yield s, "fc2", M, C, 4 * C, depth
         if s < 3:
-            total += (M // 4) * 4 * C * e16 + 2 * C * 4 * C * e16 + (M // 4) * 2 * C * 4
-            launches += 1
+            yield s, "merge", M // 4, 2 * C, 4 * C, 1
+
+
+def two_term_layers(tags):
+    """{(stage, op class)} of the tags "cls" / "cls.sN" (molnextr_amd.engine.Engine.set_op_terms, tools/study_split_terms.py --two)."""
+    out = set()
+    for tag in tags:
+        cls, _, st = tag.partition(".s")
+        out |= {(int(st) if st else s, cls) for s in ([0] if st else range(4))}
+    return out
+
+
+def gemm_algorithmic_bytes(batch=BATCH, planes=1, two=frozenset()):
+    """Average algorithmic HBM bytes per encoder GEMM launch (A + W read once, output written once, residual read
+    for the two residual epilogues) for Swin-B @384: the figure `roofline.traffic` is compared with. planes = 2 for
+    the split modes (every 16-bit operand / output is a hi and a lo plane); a layer of `two` (fp16x3m: two product terms)
+    reads ONE activation plane, and fc1 writes one when fc2 is such a layer."""
+    total, launches = 0, 0
+    for s, cls, m, n, k, cnt in encoder_gemm_layers(batch):
+        a_b = 2 * (1 if (s, cls) in two else planes)
+        w_b = 2 * planes
+        if cls == "qkv":
+            out_b, res_b = 2 * planes, 0
+        elif cls == "fc1":
+            out_b, res_b = 2 * (1 if (s, "fc2") in two else planes), 0
+        elif cls == "merge":
+            out_b, res_b = 4, 0
+        else:
+            out_b, res_b = 4, 4
+        total += cnt * (m * k * a_b + n * k * w_b + m * n * (out_b + res_b))
+        launches += cnt
     return total / launches
+
+
+def gemm_mfma_terms(split, two=frozenset()):
+    """MFMA terms executed per algorithmic product, FLOP-weighted over the encoder's Linears: 1 (one plane per operand), 3 (split
+    modes), or between 2 and 3 (fp16x3m: the layers of `two` run ah.wh + ah.wl only)."""
+    if not split:
+        return 1.0
+    ex = sum((2 if (s, cls) in two else 3) * m * n * k * cnt for s, cls, m, n, k, cnt in encoder_gemm_layers())
+    return ex / sum(m * n * k * cnt for _, _, m, n, k, cnt in encoder_gemm_layers())
 
 
 def host_cpu_info():
@@ -351,8 +387,11 @@ def main():
     ap.add_argument("--mode", default="pipeline", choices=["pipeline", "batch"])
     ap.add_argument("--beam", type=int, default=1, help="beam size; > 1 times BASELINE config 5 (one batch at a time)")
     ap.add_argument("--max-len", type=int, default=480)
-    ap.add_argument("--dtype", default="fp16x3", choices=["fp16x3", "bf16x3", "bf16", "fp16", "fp32"],
-                    help="encoder operand mode; fp16x3 (default) is the fastest one that is token-exact vs the reference")
+    ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["fp16x3", "fp16x3m", "bf16x3", "bf16", "fp16", "fp32"],
+                    help="encoder operand mode. fp16x3: three MFMA terms per product everywhere, fp32-class features (5e-6); fp16x3m: "
+                         "the same with the Linear layers of molnextr_amd.engine.FP16X3M_TWO_TERM on two terms (activation lo plane "
+                         "dropped): log-probs within 5e-4 of the reference's (north_star: 1e-3), every token / atom / bond still equal "
+                         "to the reference's on both fixture checkpoints (tests/test_gpu_pixels.py)")
     ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "512")),
                     help="images per encoder launch group (a multiple of 32; decode batches stay 32). 512 = 16 reference "
                          "batches: every Linear of Swin stage 3 then has a WHOLE number of rounds of 256 output tiles of 256x256 "
@@ -476,8 +515,9 @@ def main():
             eng.encode(imgs[i * eb:(i + 1) * eb].contiguous())
         iso = eng.profile_read_all()
         eng.profile(False)
-        split = args.dtype in ("fp16x3", "bf16x3")
-        terms = 3 if split else 1
+        split = args.dtype in ("fp16x3", "fp16x3m", "bf16x3")
+        two = two_term_layers(FP16X3M_TWO_TERM) if args.dtype == "fp16x3m" else frozenset()
+        terms = round(gemm_mfma_terms(split, two), 4)      # FLOP-weighted average over the encoder's Linears
 
         def family(prof, kinds):
             ms = sum(prof[k][0] for k in kinds)
@@ -500,12 +540,15 @@ def main():
         # operands, ~30 ms, measured now): the encoder GEMMs are power-limited, the nominal 2.5 PFLOP/s assumes 2.4 GHz
         sus_tf, sus_mhz = eng.probe_mfma(30)
         mfma = {"fp16x3": "v_mfma_f32_16x16x32_f16 x 3 terms", "bf16x3": "v_mfma_f32_16x16x32_bf16 x 3 terms",
+                "fp16x3m": f"v_mfma_f32_16x16x32_f16 x 3 terms, x 2 in {'/'.join(FP16X3M_TWO_TERM)}: {terms} on average",
                 "bf16": "v_mfma_f32_16x16x32_bf16", "fp16": "v_mfma_f32_16x16x32_f16", "fp32": "v_mfma_f32_16x16x4_f32"}[args.dtype]
         roofline = {"kernel": f"mnx::gemm_tn_* + mnx::gemm256*_kernel ({mfma}, all encoder Linear layers)",
                     "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "work": "algorithmic FLOP = 2*M*N*K per launch",
                     "mfma_terms": terms, "frac_of_peak_executed": round(terms * achieved / PEAK_BF16_TFLOPS, 4),
+                    # executed rate / what a register-only MFMA loop on random operands sustains on this device right now
+                    "frac_of_sustained": round(terms * achieved / sus_tf, 4) if sus_tf > 0 else None,
                     # the chip clocks to its power budget: the persistent GEMM kernel's own stamps (shader cycles / wall ticks,
                     # every launch of the timed job) and what a register-only MFMA loop on random operands sustains right now
                     "clock": {"gemm_shader_mhz_live": round(gemm_mhz, 0), "nominal_mhz": 2400,
@@ -516,7 +559,7 @@ def main():
                               "frac_of_sustained_executed": round(terms * achieved / sus_tf, 4) if sus_tf > 0 else None,
                               "what": "mnx_gemm_clock / mnx_probe_mfma, both measured in this run (include/molnextr_hip.h)"},
                     "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb, 2 if split else 1)),
+                    "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(eb, 2 if split else 1, two)),
                     "images_per_launch": eb,
                     "launches": int(launches), "avg_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
                     "flop_per_launch_avg": round(gemm_flop / max(launches, 1)),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNX_ABI_VERSION 6
+#define MNX_ABI_VERSION 7
 
 typedef struct mnx_engine mnx_engine;
 
@@ -52,8 +52,22 @@ typedef enum {
  *                  encoder output is reported as MNX_ERR_RANGE by mnx_predict / mnx_predict_beam and by
  *                  mnx_encoder_status; BF16X3 has the fp32 range and ~2^-16 relative product error;
  *   FP32           every encoder operand in fp32 on the exact-fp32 matrix instructions (1/16 of the bf16 rate): the
- *                  reference-arithmetic mode the split modes are checked against. */
-enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1, MNX_DTYPE_FP32 = 2, MNX_DTYPE_BF16X3 = 3, MNX_DTYPE_FP16X3 = 4 };
+ *                  reference-arithmetic mode the split modes are checked against;
+ *   FP16X3M        FP16X3 with a per-stage, per-op-class term count ("M" = mixed): the op classes of
+ *                  MNX_FP16X3M_TWO_TERM_BY_STAGE evaluate
+ *                  a.w as ah.wh + ah.wl — the ACTIVATION's lo plane is neither written by its producer nor read nor
+ *                  multiplied; the weight keeps both planes (its rounding is systematic over every token, the
+ *                  activation's is noise: dropping ah.wl instead costs 3x the error). Two thirds of the matrix work and half
+ *                  the activation bytes in those classes; log-probs within 5e-4 of the reference's (north_star: 1e-3),
+ *                  tokens / atoms / bonds exact on both fixture checkpoints (tests/test_gpu_pixels.py).
+ *                  Same weights, range and MNX_ERR_RANGE behaviour as FP16X3. mnx_set_op_terms changes the table. */
+enum { MNX_DTYPE_BF16 = 0, MNX_DTYPE_FP16 = 1, MNX_DTYPE_FP32 = 2, MNX_DTYPE_BF16X3 = 3, MNX_DTYPE_FP16X3 = 4,
+       MNX_DTYPE_FP16X3M = 5 };
+/* op classes of the split modes (bits of mnx_set_split_terms / mnx_set_op_terms) */
+enum { MNX_OP_QKV = 1, MNX_OP_ATTN = 2, MNX_OP_PROJ = 4, MNX_OP_FC1 = 8, MNX_OP_FC2 = 16, MNX_OP_MERGE = 32 };
+/* FP16X3M's table: the two-term op classes of Swin-B's stages 1..4 (the patch-merging reduction BEHIND stage s counts as
+ * stage s). tools/study_split_terms.py --two is the CPU emulation that picked it, tests/test_gpu_pixels.py the gate. */
+#define MNX_FP16X3M_TWO_TERM_BY_STAGE { MNX_OP_FC1 | MNX_OP_FC2, MNX_OP_FC1 | MNX_OP_FC2, MNX_OP_FC1 | MNX_OP_FC2, MNX_OP_FC1 | MNX_OP_FC2 }
 
 /* Architecture + capacity. Defaults of the reference inference config are in the comments
  * (MolNexTR/models/transformers.py:547-551 swin_base; MolNexTR/model.py:50-81; MolNexTR/utils.py:25). */
@@ -114,11 +128,20 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
  * item < 0 disables. */
 int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst);
 
-/* Test / measurement aid for the split modes (compute_dtype BF16X3 / FP16X3): choose per op class whether its products
- * are evaluated with all three terms (bit set, the default) or with the hi.hi term alone, i.e. as the plain 16-bit mode
- * would. Bits: 1 qkv Linear, 2 window attention (QK^T and PV), 4 proj Linear, 8 fc1, 16 fc2, 32 patch-merging reduction.
+/* Test / measurement aid for the split modes (compute_dtype BF16X3 / FP16X3 / FP16X3M): choose per op class whether its
+ * products are evaluated with the mode's own term count (bit set, the default: three, or two for the classes of
+ * mnx_set_op_terms) or with the hi.hi term alone, i.e. as the plain 16-bit mode would. Bits: MNX_OP_* — 1 qkv Linear,
+ * 2 window attention (QK^T and PV), 4 proj Linear, 8 fc1, 16 fc2, 32 patch-merging reduction.
  * Used by tests/test_gpu_pixels.py to measure which op classes the feature error comes from. No effect in other modes. */
 int mnx_set_split_terms(mnx_engine* h, int32_t mask);
+
+/* compute_dtype FP16X3 / FP16X3M only: the Linear op classes (MNX_OP_* bits, not MNX_OP_ATTN) of encoder stage `stage`
+ * (0-based; -1 = every stage) that run on TWO terms (ah.wh + ah.wl). FP16X3 starts with none, FP16X3M with
+ * MNX_FP16X3M_TWO_TERM_BY_STAGE; the weights are the same in both, so one engine can be measured under several tables
+ * (tests/test_gpu_pixels.py; tools/study_split_terms.py is the CPU emulation). A 16-bit activation whose only consumer runs on
+ * two terms is written as one plane. Takes effect at the next mnx_encode / mnx_predict call; not to be changed while one is
+ * in flight. */
+int mnx_set_op_terms(mnx_engine* h, int32_t stage, int32_t two_term_mask);
 
 /* Synchronises `stream` and reports (then clears) whether any mnx_encode since the last call produced a non-finite
  * feature row — the only way the fp16 operand modes can fail on a checkpoint whose activations exceed 65504. */
@@ -249,7 +272,9 @@ int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C
 
 /* The same for the split modes (the engine's compute_dtype must be BF16X3 / FP16X3): A, W (and C for epi 0 / 1) point at
  * hi planes, a_lo / w_lo / c_lo are the ELEMENT offsets of the lo planes, C = epi(oscale * (Ah.Wh + Ah.Wl + Al.Wh) + bias)
- * with the exact-erf GELU; terms = 3, or 1 for Ah.Wh alone. */
+ * with the exact-erf GELU; terms = 3, 2 (Ah.Wh + Ah.Wl: a_lo is ignored; FP16X3 / FP16X3M engines) or 1 (Ah.Wh alone).
+ * Test aids in `epi`: | 0x100 the persistent fp32-output kernel of gemm_res.hip, | 0x200 the 128x128 kernel whatever the
+ * dispatch would choose, | 0x400 (epi 0 / 1) write the hi output plane only (c_lo ignored). */
 int mnx_gemm16_split(mnx_engine* h, int32_t epi, const void* A, int64_t a_lo, const void* W, int64_t w_lo, float oscale,
                      void* C, int64_t c_lo, const float* bias, int32_t M, int32_t N, int32_t K, int32_t terms,
                      void* stream);

@@ -182,7 +182,8 @@ hipError_t launch_patch_embed(const float* img, const float* w_t, const float* b
 //     MERGE=true fuses the PatchMerging 2x2 gather (reference transformers.py:325-333): logical row
 //     (b, y2, x2) is the concat of x[b, 2y2+dy, 2x2+dx, :] for (dy,dx) = (0,0),(1,0),(0,1),(1,1).
 // =============================================================================================
-//     SPLIT (dtypes BF16X3 / F16X3): the 16-bit output is two planes, hi and lo = v - hi (y_lo elements behind).
+//     SPLIT (dtypes BF16X3 / F16X3): the 16-bit output is two planes, hi and lo = v - hi (y_lo elements behind); y_lo == 0
+//     inside the kernel means "hi plane only" (launch_layernorm16 planes == 1: the consumer runs on two terms).
 //     LPR = lanes per row: 64, or 32 for C <= 128 (stage 1: a 64-lane wave would keep half its lanes idle on the largest
 //     M of the encoder — two rows per wave instead; the butterfly sums are bit-identical, the upper half only added zeros).
 template <int LPR>
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* __restric
                     v4 hi, lo;
                     split16x4<T>(o, hi, lo);
                     *(v4*)(y16 + (size_t)row * C + e) = hi;
-                    *(v4*)(y16 + y_lo + (size_t)row * C + e) = lo;
+                    if (y_lo) *(v4*)(y16 + y_lo + (size_t)row * C + e) = lo;
                 } else {
                     v4 o4 = {(T)o[0], (T)o[1], (T)o[2], (T)o[3]};
                     *(v4*)(y16 + (size_t)row * C + e) = o4;
@@ -303,8 +304,10 @@ static void ln_dispatch(dim3 grid, hipStream_t s, const float* x, const float* g
 template <bool MERGE>
 static hipError_t ln_by_dtype(int dtype, dim3 grid, hipStream_t s, const float* x, const float* gamma, const float* beta,
                               void* y16, float* y32, int M, int C, float eps, int H, int W, int Cin, size_t y_lo,
-                              int* flag) {
-    if (dt_split(dtype) && y16 && y_lo == 0) return hipErrorInvalidValue;
+                              int* flag, int planes) {
+    if (planes != 1 && planes != 2) return hipErrorInvalidValue;
+    if (dt_split(dtype) && y16 && planes == 2 && y_lo == 0) return hipErrorInvalidValue;
+    if (planes == 1) y_lo = 0;
     switch (dtype) {
         case MNX_DT_F16: ln_dispatch<f16_t, MERGE, false>(grid, s, x, gamma, beta, (f16_t*)y16, y32, M, C, eps, H, W, Cin, 0, flag); break;
         case MNX_DT_F32: ln_dispatch<float, MERGE, false>(grid, s, x, gamma, beta, (float*)y16, y32, M, C, eps, H, W, Cin, 0, flag); break;
@@ -317,16 +320,16 @@ static hipError_t ln_by_dtype(int dtype, dim3 grid, hipStream_t s, const float* 
 }
 
 hipError_t launch_layernorm16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, float* y32,
-                              int M, int C, float eps, hipStream_t s, size_t y_lo, int* nonfinite_flag) {
+                              int M, int C, float eps, hipStream_t s, size_t y_lo, int* nonfinite_flag, int planes) {
     if (C > 2048 || (C & 3)) return hipErrorInvalidValue;
-    return ln_by_dtype<false>(dtype, dim3((M + 3) / 4), s, x, gamma, beta, y16, y32, M, C, eps, 0, 0, 0, y_lo, nonfinite_flag);
+    return ln_by_dtype<false>(dtype, dim3((M + 3) / 4), s, x, gamma, beta, y16, y32, M, C, eps, 0, 0, 0, y_lo, nonfinite_flag, planes);
 }
 
 hipError_t launch_merge_ln16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, int B, int H,
-                             int W, int C, float eps, hipStream_t s, size_t y_lo) {
+                             int W, int C, float eps, hipStream_t s, size_t y_lo, int planes) {
     if (4 * C > 2048 || (C & 3) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
     const int M = B * (H / 2) * (W / 2);
-    return ln_by_dtype<true>(dtype, dim3((M + 3) / 4), s, x, gamma, beta, y16, nullptr, M, 4 * C, eps, H, W, C, y_lo, nullptr);
+    return ln_by_dtype<true>(dtype, dim3((M + 3) / 4), s, x, gamma, beta, y16, nullptr, M, 4 * C, eps, H, W, C, y_lo, nullptr, planes);
 }
 
 template <typename T>

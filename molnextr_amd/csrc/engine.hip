@@ -69,7 +69,9 @@ struct mnx_engine {
     float *xa = nullptr, *xb = nullptr;              // fp32 residual stream ping-pong
     void *xn16 = nullptr, *qkv16 = nullptr, *attn16 = nullptr, *h16 = nullptr;
     size_t xn_lo = 0, qkv_lo = 0, attn_lo = 0, h_lo = 0;   // split modes: element offset of each buffer's lo plane
-    int split_mask = SPL_ALL;                               // op classes evaluated with all three product terms
+    int dt = 0;                                             // kernels.h MNX_DT_* the encoder kernels run (FP16X3M -> MNX_DT_F16X3)
+    int split_mask = SPL_ALL;                               // op classes evaluated with their full term count (others: hi.hi only)
+    int two_mask[4] = {0, 0, 0, 0};                         // per stage: op classes whose full term count is TWO (ah.wh + ah.wl): FP16X3M, mnx_set_op_terms
     int* enc_flag = nullptr;                                // device: set when the final LayerNorm sees a non-finite row
     float* zero_bias = nullptr;                             // [2 * widest C] zeros: the bias of the patch-merging reductions
     int zero_bias_n = 0;
@@ -195,7 +197,7 @@ struct Packer {
             problems.push_back("staging too small for " + name);
             return w;
         }
-        const int dt = h->cfg.compute_dtype;
+        const int dt = h->dt;
         float scale = 1.f;
         if (dt == MNX_DT_F16X3) {
             // fp16 split: store 2^k W with max |2^k W| in [2^14, 2^15) — the lo plane of a weight of typical size
@@ -253,7 +255,7 @@ int check_cfg(const mnx_config& c, std::string& why) {
     if (c.max_len < 1 || c.max_len > 512) return bad("max_len must be 1..512");
     if (c.max_batch < 1) return bad("max_batch < 1");
     if (c.max_atoms < 1 || c.max_atoms > 256) return bad("max_atoms must be 1..256");
-    if (c.compute_dtype < MNX_DTYPE_BF16 || c.compute_dtype > MNX_DTYPE_FP16X3) return bad("compute_dtype");
+    if (c.compute_dtype < MNX_DTYPE_BF16 || c.compute_dtype > MNX_DTYPE_FP16X3M) return bad("compute_dtype");
     if (c.dec_slots < 0 || c.dec_slots > MAX_SLOTS || (c.dec_slots % ROW_TILE) != 0) return bad("dec_slots");
     if (c.pe_len < ROW_TILE) return bad("pe_len too small");
     return MNX_OK;
@@ -322,6 +324,13 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     mnx_engine* h = new mnx_engine();
     h->cfg = *cfg;
     h->device = device;
+    // FP16X3M = the FP16X3 kernels and weights with the op classes of MNX_FP16X3M_TWO_TERM on two product terms
+    h->dt = cfg->compute_dtype == MNX_DTYPE_FP16X3M ? MNX_DT_F16X3 : cfg->compute_dtype;
+    if (cfg->compute_dtype == MNX_DTYPE_FP16X3M) {
+        const int by_stage[4] = MNX_FP16X3M_TWO_TERM_BY_STAGE;
+        // the table is written for Swin-B's four stages; a shallower encoder (the tests' tiny one) keeps its LAST stages' rows
+        for (int st = 0; st < cfg->n_stages; ++st) h->two_mask[st] = by_stage[st + 4 - cfg->n_stages];
+    }
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
     // MNX_ENC_CUS=n (default 256): the encoder's persistent kernels (gemm256x3_kernel: one 150 KB-LDS workgroup per CU for the
@@ -556,15 +565,15 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->xa = (float*)P.dalloc(MB * L0 * C0 * 4);
     h->xb = (float*)P.dalloc(MB * L0 * C0 * 4 / 2);
     // operand bytes per element: 2 (bf16 / fp16), 4 (fp32 parity mode, or the two 16-bit planes of the split modes)
-    const size_t es = dt_size(c.compute_dtype);
+    const size_t es = dt_size(h->dt);
     // split modes: the lo plane follows the hi plane after PLANE_SKEW extra elements, so that the two planes of a row
     // are not a large power of two apart (same HBM channel / bank for every hi / lo pair of a stream)
-    const size_t skew = dt_split(c.compute_dtype) ? PLANE_SKEW : 0;
+    const size_t skew = dt_split(h->dt) ? PLANE_SKEW : 0;
     h->xn16 = P.dalloc(MB * max_xn * es + skew * 2);
     h->qkv16 = P.dalloc(MB * max_qkv * es + skew * 2);
     h->attn16 = P.dalloc(MB * max_xn * es + skew * 2);
     h->h16 = P.dalloc(MB * max_h * es + skew * 2);
-    if (dt_split(c.compute_dtype)) {
+    if (dt_split(h->dt)) {
         h->xn_lo = MB * max_xn + skew; h->qkv_lo = MB * max_qkv + skew; h->attn_lo = MB * max_xn + skew; h->h_lo = MB * max_h + skew;
     }
     {   // the reference's PatchMerging.reduction has no bias; every GEMM kernel adds this vector instead, so that the rows
@@ -667,6 +676,19 @@ int mnx_set_split_terms(mnx_engine* h, int32_t mask) {
     return MNX_OK;
 }
 
+int mnx_set_op_terms(mnx_engine* h, int32_t stage, int32_t two_term_mask) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (h->dt != MNX_DT_F16X3) { h->err = "mnx_set_op_terms: compute_dtype must be FP16X3 or FP16X3M"; return MNX_ERR_INVALID_ARG; }
+    if (stage < -1 || stage >= h->cfg.n_stages) { h->err = "mnx_set_op_terms: stage must be -1 (all) or 0..n_stages-1"; return MNX_ERR_INVALID_ARG; }
+    if (two_term_mask < 0 || two_term_mask > SPL_ALL || (two_term_mask & SPL_ATTN)) {
+        h->err = "mnx_set_op_terms: mask must be a subset of the Linear classes (1 qkv, 4 proj, 8 fc1, 16 fc2, 32 merge)";
+        return MNX_ERR_INVALID_ARG;
+    }
+    for (int st = 0; st < h->cfg.n_stages; ++st)
+        if (stage < 0 || stage == st) h->two_mask[st] = two_term_mask;
+    return MNX_OK;
+}
+
 int mnx_encoder_status(mnx_engine* h, int32_t* nonfinite, void* stream) {
     if (!h || !nonfinite) return MNX_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -698,7 +720,7 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     if (B > h->cfg.max_batch) { h->err = "mnx_encode: B exceeds max_batch"; return MNX_ERR_CAPACITY; }
     hipStream_t s = (hipStream_t)stream;
     const mnx_config& c = h->cfg;
-    const int dt = c.compute_dtype;
+    const int dt = h->dt;
     HIPCHK(h, hipSetDevice(h->device));
     int Hh = c.img_size / c.patch, Ww = Hh, C = c.embed_dim;
     float* cur = h->xa;
@@ -735,42 +757,50 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     const bool split = dt_split(dt);
     // split modes: a_lo / c_lo = lo-plane offsets of the activation buffers, cls = the op class whose bit of split_mask
     // selects three product terms (default) or the hi.hi term alone (error-budget aid)
+    // terms of an op class: its full count (3, or 2 for the classes of two_mask) or hi.hi alone. A 16-bit activation is
+    // written as ONE plane when its consumer runs on two terms (planes_for): half the bytes out of the producer, half into
+    // the consumer; the hi plane is the same bits either way.
+    int stage_now = 0;
+    auto terms_of = [&](int cls) { return !(h->split_mask & cls) ? 1 : (h->two_mask[stage_now] & cls) ? 2 : 3; };
+    auto planes_for = [&](int consumer_cls) { return split && terms_of(consumer_cls) == 2 ? 1 : 2; };
     auto gemm = [&](int epi, const void* A, size_t a_lo, const W16& Wt, void* Cc, size_t c_lo, const float* bias,
-                    const float* resid, int M, int N, int K, int cls) -> hipError_t {
+                    const float* resid, int M, int N, int K, int cls, int c_planes = 2) -> hipError_t {
         SplitArgs sp;
         sp.a_lo = a_lo; sp.w_lo = Wt.lo; sp.c_lo = c_lo; sp.oscale = Wt.oscale;
-        sp.terms = (h->split_mask & cls) ? 3 : 1;
+        sp.terms = terms_of(cls);
+        sp.c_planes = c_planes;
         // kind 4: the Linear layers of the blocks with C >= 512 (Swin-B stages 3 and 4, the MFMA-bound shapes); kind 0: the rest
         return timed((cls != SPL_MERGE && std::min(N, K) >= 512) ? 4 : 0, 2.0 * (double)M * (double)N * (double)K,
                      [&]() { return launch_gemm16(dt, epi, A, Wt.p, Cc, bias, resid, M, N, K, s, split ? &sp : nullptr); });
     };
-    auto ln = [&](const float* x, const float* g, const float* b, void* y16, float* y32, int M, int Cc) -> hipError_t {
-        return timed(1, (double)M * Cc * (4.0 + (y16 ? es : 0.0) + (y32 ? 4.0 : 0.0)),
-                     [&]() { return launch_layernorm16(dt, x, g, b, y16, y32, M, Cc, 1e-5f, s, h->xn_lo, y32 ? h->enc_flag : nullptr); });
+    auto ln = [&](const float* x, const float* g, const float* b, void* y16, float* y32, int M, int Cc, int planes = 2) -> hipError_t {
+        return timed(1, (double)M * Cc * (4.0 + (y16 ? es * planes / 2 : 0.0) + (y32 ? 4.0 : 0.0)),
+                     [&]() { return launch_layernorm16(dt, x, g, b, y16, y32, M, Cc, 1e-5f, s, h->xn_lo, y32 ? h->enc_flag : nullptr, planes); });
     };
     HIPCHK(h, timed(3, (double)B * (3.0 * c.img_size * c.img_size + (double)Hh * Ww * C) * 4.0,
                     [&]() { return launch_patch_embed(images, h->pe_wt, h->pe_b, h->pe_g, h->pe_beta, cur, B, c.img_size, C, s); }));
     HIPCHK(h, tap((size_t)B * Hh * Ww * C));
     for (int si = 0; si < c.n_stages; ++si) {
         StageW& st = h->stages[si];
+        stage_now = si;
         const int M = B * Hh * Ww;
         for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
             const BlockW& w = st.blocks[bi];
             const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
-            HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C));
+            HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C, planes_for(SPL_QKV)));
             HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, h->xn_lo, w.qkv_w, h->qkv16, h->qkv_lo, w.qkv_b, nullptr, M, 3 * C, C, SPL_QKV));
             HIPCHK(h, timed(2, (double)M * C * 4.0 * es, [&]() {
                 return launch_window_attn(dt, h->qkv16, w.table, h->attn16, B, Hh, Ww, C, st.heads, shift, s, h->qkv_lo,
                                           h->attn_lo, (h->split_mask & SPL_ATTN) ? 3 : 1);
             }));
             HIPCHK(h, gemm(EPI_RESID_F32, h->attn16, h->attn_lo, w.proj_w, cur, 0, w.proj_b, cur, M, C, C, SPL_PROJ));
-            HIPCHK(h, ln(cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C));
-            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, h->xn_lo, w.fc1_w, h->h16, h->h_lo, w.fc1_b, nullptr, M, 4 * C, C, SPL_FC1));
+            HIPCHK(h, ln(cur, w.ln2_g, w.ln2_b, h->xn16, nullptr, M, C, planes_for(SPL_FC1)));
+            HIPCHK(h, gemm(EPI_GELU_16, h->xn16, h->xn_lo, w.fc1_w, h->h16, h->h_lo, w.fc1_b, nullptr, M, 4 * C, C, SPL_FC1, planes_for(SPL_FC2)));
             HIPCHK(h, gemm(EPI_RESID_F32, h->h16, h->h_lo, w.fc2_w, cur, 0, w.fc2_b, cur, M, C, 4 * C, SPL_FC2));
             HIPCHK(h, tap((size_t)M * C));
         }
         if (si + 1 < c.n_stages) {
-            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s, h->xn_lo));
+            HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s, h->xn_lo, planes_for(SPL_MERGE)));
             HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, h->xn_lo, st.m_w, other, 0, h->zero_bias, nullptr, M / 4, 2 * C, 4 * C, SPL_MERGE));
             std::swap(cur, other);
             Hh /= 2; Ww /= 2; C *= 2;
@@ -1400,7 +1430,7 @@ int mnx_gemm16(mnx_engine* h, int32_t epi, const void* A, const void* W, void* C
                int32_t N, int32_t K, void* stream) {
     if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    const int dt = dt_base(h->cfg.compute_dtype);
+    const int dt = dt_base(h->dt);
     if (!bias && N <= h->zero_bias_n) bias = h->zero_bias;
     if (epi & 0x100) {      // test aid: the persistent fp32-output kernel (gemm_res.hip) whatever the dispatch would choose
         epi &= 0xff;
@@ -1418,23 +1448,34 @@ int mnx_gemm16_split(mnx_engine* h, int32_t epi, const void* A, int64_t a_lo, co
                      void* C, int64_t c_lo, const float* bias, int32_t M, int32_t N, int32_t K, int32_t terms,
                      void* stream) {
     if (!h || !A || !W || !C) return MNX_ERR_INVALID_ARG;
-    if (!dt_split(h->cfg.compute_dtype)) { h->err = "mnx_gemm16_split: the engine's compute_dtype is not a split mode"; return MNX_ERR_INVALID_ARG; }
+    if (!dt_split(h->dt)) { h->err = "mnx_gemm16_split: the engine's compute_dtype is not a split mode"; return MNX_ERR_INVALID_ARG; }
     if (a_lo < 0 || w_lo < 0 || c_lo < 0) { h->err = "mnx_gemm16_split: negative plane offset"; return MNX_ERR_INVALID_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     if (!bias) {            // the kernels take a bias vector unconditionally: the engine's zero vector stands in
         if (N > h->zero_bias_n) { h->err = "mnx_gemm16_split: bias == NULL needs N <= 2 * the widest stage"; return MNX_ERR_CAPACITY; }
         bias = h->zero_bias;
     }
+    if (terms < 1 || terms > 3 || (terms == 2 && h->dt != MNX_DT_F16X3)) {
+        h->err = "mnx_gemm16_split: terms must be 1, 3 or (FP16X3 / FP16X3M only) 2";
+        return MNX_ERR_INVALID_ARG;
+    }
     SplitArgs sp;
     sp.a_lo = (size_t)a_lo; sp.w_lo = (size_t)w_lo; sp.c_lo = (size_t)c_lo; sp.oscale = oscale; sp.terms = terms;
+    if (epi & 0x400) { sp.c_planes = 1; epi &= ~0x400; }      // 16-bit epilogues: the hi output plane only
+    if (epi & 0x200) {      // test aid: the 128x128 kernel whatever the dispatch would choose
+        epi &= 0xff;
+        HIPCHK(h, launch_gemm16_tile128(h->dt, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr, M, N, K,
+                                        (hipStream_t)stream, &sp));
+        return MNX_OK;
+    }
     if (epi & 0x100) {      // test aid: gemm_res.hip whatever the dispatch would choose
         epi &= 0xff;
-        if (!gemm_res_supports(h->cfg.compute_dtype, epi, M, N, K)) { h->err = "mnx_gemm16_split: not supported by gemm_res"; return MNX_ERR_INVALID_ARG; }
-        HIPCHK(h, launch_gemm_res(h->cfg.compute_dtype, epi, A, W, (float*)C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
+        if (!gemm_res_supports(h->dt, epi, M, N, K)) { h->err = "mnx_gemm16_split: not supported by gemm_res"; return MNX_ERR_INVALID_ARG; }
+        HIPCHK(h, launch_gemm_res(h->dt, epi, A, W, (float*)C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr,
                                   M, N, K, (hipStream_t)stream, &sp));
         return MNX_OK;
     }
-    HIPCHK(h, launch_gemm16(h->cfg.compute_dtype, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr, M, N,
+    HIPCHK(h, launch_gemm16(h->dt, epi, A, W, C, bias, epi == EPI_RESID_F32 ? (const float*)C : nullptr, M, N,
                             K, (hipStream_t)stream, &sp));
     return MNX_OK;
 }

@@ -116,7 +116,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BN / 32][4], char* sm
 
 // Epilogue of the split-operand modes (kernels.h SplitArgs): C = epi(oscale * acc + bias) with the exact-erf GELU (the
 // point of these modes is fp32-class results), 16-bit outputs written as TWO planes (hi, then lo = v - hi, c_lo elements
-// behind) through the same LDS transposition; fp32 outputs go through gemm_epilogue unchanged.
+// behind; SplitArgs::c_planes == 1: the hi plane only) through the same LDS transposition; fp32 outputs go through
+// gemm_epilogue unchanged.
 template <typename T, int EPI, int BN>
 __device__ __forceinline__ void gemm_epilogue_split(f32x4 (&acc)[BN / 32][4], char* smem, void* Cout,
                                                     const float* __restrict__ bias, const float* resid, int M, int N,
@@ -152,6 +153,7 @@ __device__ __forceinline__ void gemm_epilogue_split(f32x4 (&acc)[BN / 32][4], ch
     }
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
+        if (plane == 1 && sp.c_planes == 1) break;     // the consumer runs on two terms: hi plane only
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int nl = wn * (BN / 2) + nt * 16 + fg * 4;
@@ -201,12 +203,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         w_ptr[i] = W + (size_t)rw * K + ld_c * 8;
     }
     // split modes: K-tile j of the loop is term j % 3 of K-tile j / 3: (A hi, W lo), (A hi, W hi), (A lo, W hi) — the one
-    // order in which every encoder GEMM kernel accumulates the three terms (see gemm_tn_glds_kernel)
+    // order in which every encoder GEMM kernel accumulates the three terms (see gemm_tn_glds_kernel); two terms: the first
+    // two of them
     const int nterm = SPLIT ? sp.terms : 1;
     const int nk = ((K + BK - 1) / BK) * nterm;
     Stage<T> st;
     auto load_g = [&](int j) {
-        const int kt = nterm == 3 ? j / 3 : j, term = nterm == 3 ? j - kt * 3 : 1;
+        const int kt = nterm > 1 ? j / nterm : j, term = nterm > 1 ? j - kt * nterm : 1;
         const int k0 = kt * BK;
         const size_t ka = (size_t)k0 + (term == 2 ? sp.a_lo : 0), kw = (size_t)k0 + (term == 0 ? sp.w_lo : 0);
         const bool ok = (k0 + ld_c * 8) < K;  // K % 8 == 0: a chunk is all-in or all-out
@@ -307,6 +310,10 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
     //     s1     A hi . W lo    W hi (kt)                -> the other W buffer
     //     s2     A hi . W hi    A lo (kt)                -> the other A buffer
     //     s3     A lo . W hi    A hi, W lo (kt + 1)      -> the buffers s1 / s2 released
+    // Split modes with two terms (the activation's lo plane dropped): K-tile kt is two steps and 3 tile fills:
+    //     s1     A hi . W lo    W hi (kt)                -> the other W buffer
+    //     s2     A hi . W hi    A hi (kt + 1)            -> the other A buffer;  W lo (kt + 1) -> the buffer s1 released
+    // (A hi alternates between the two A buffers by K-tile; W lo is always in W buffer 0, W hi in 1.)
     // The term order hi.lo, hi.hi, lo.hi is the one in which gemm256x3_kernel (gemm256.hip), whose phases are chained by
     // register reuse, can accumulate EVERY row; launch_gemm16 splits a layer's rows between the two kernels by batch size,
     // and with the same order of fp32 additions per output element in both, an image's features do not depend on the
@@ -330,9 +337,9 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = K / BK, nsteps = nk * nterm;
-    const bool three = SPLIT && nterm == 3;
+    const bool three = SPLIT && nterm == 3, two = SPLIT && nterm == 2;
     issue_a(0, 0);
-    issue_w(three ? sp.w_lo : (size_t)0, 0);
+    issue_w((three || two) ? sp.w_lo : (size_t)0, 0);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     int il = 0;                            // three-term schedule: W buffer holding the current K-tile's W lo (W hi: the other one; A hi is always in A buffer 0, A lo in 1)
@@ -346,6 +353,15 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(const T* __restrict__
             else {
                 ia = 1; iw = il ^ 1;
                 if (kt + 1 < nk) { issue_a(k0 + BK, 0); issue_w(k0 + BK + sp.w_lo, il); }
+            }
+        } else if (two) {
+            const int kt = j >> 1;
+            const size_t k0 = (size_t)kt * BK;
+            ia = kt & 1;
+            if ((j & 1) == 0) { iw = 0; issue_w(k0, 1); }
+            else {
+                iw = 1;
+                if (kt + 1 < nk) { issue_a(k0 + BK, ia ^ 1); issue_w(k0 + BK + sp.w_lo, 0); }
             }
         } else {
             ia = iw = j & 1;
@@ -497,7 +513,7 @@ hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* 
     if ((K & 7) || (N & 7) || M <= 0) return hipErrorInvalidValue;
     if (dtype == MNX_DT_F32) return launch_f32(epi, A, W, C, bias, resid, M, N, K, s);
     if (dt_split(dtype)) {
-        if (!sp || (sp->terms != 1 && sp->terms != 3)) return hipErrorInvalidValue;
+        if (!sp || sp->terms < 1 || sp->terms > 3 || (sp->c_planes != 1 && sp->c_planes != 2)) return hipErrorInvalidValue;
         return dtype == MNX_DT_F16X3 ? launch_t<f16_t, true>(epi, A, W, C, bias, resid, M, N, K, s, *sp)
                                      : launch_t<bf16_t, true>(epi, A, W, C, bias, resid, M, N, K, s, *sp);
     }
@@ -508,7 +524,7 @@ hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* 
 
 // rows that launch_gemm16 gives to gemm256x3_kernel (the rest goes to the 128x128 kernel); 0 = none
 static int x3_main_rows(int dtype, int epi, int M, int N, int K, int terms) {
-    if (!dt_split(dtype) || terms != 3 || !gemm256x3_supports(dtype, epi, M, N, K)) return 0;
+    if (!dt_split(dtype) || (terms != 3 && !(terms == 2 && dtype == MNX_DT_F16X3)) || !gemm256x3_supports(dtype, epi, M, N, K)) return 0;
     const int tn = N / 256, tm = M / 256, tiles = tm * tn, cus = persistent_cus();
     int tm_main = tm;
     if (tiles % cus != 0 && (tiles % cus) * 10 < cus * 8) tm_main = (tiles / cus) * cus / tn;
@@ -526,7 +542,7 @@ const char* gemm16_route(int dtype, int epi, int M, int N, int K, int terms, boo
 
 hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                          const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
-    // Split modes with all three terms: the six-phase 256x256 kernel (gemm256x3_kernel) takes the rows that fill whole
+    // Split modes with three (two) terms: the six- (four-) phase 256x256 kernel (gemm256x3_kernel) takes the rows that fill whole
     // rounds of 256 tiles (one workgroup per CU walks its tiles in rounds; a last round that is at least 80 % full is
     // taken too), the 128x128 kernel (2-3 workgroups per CU) the remaining rows. Shape-only, like everything below.
     if (const int r0 = sp ? x3_main_rows(dtype, epi, M, N, K, sp->terms) : 0) {

@@ -293,12 +293,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 }
 
 // =====================================================================================================================
-// gemm256x3_kernel — the split-operand form with all three product terms (dtypes BF16X3 / F16X3, SplitArgs::terms == 3).
+// gemm256x3_kernel — the split-operand form (dtypes BF16X3 / F16X3) with all THREE product terms (SplitArgs::terms == 3:
+// ah.wl + ah.wh + al.wh) or with TWO (terms == 2: ah.wl + ah.wh — the activation's lo plane is neither read nor multiplied;
+// the weight keeps both planes. compute_dtype FP16X3M runs the op classes on two terms whose error budget allows it).
 //
-// Streaming the three terms of a K-tile as three complete K-tiles costs 12 slot fills and 72 fragment reads per 192 MFMAs
-// of a wave, although A hi and W hi are each needed twice. This kernel keeps the four operand slabs of ONE K-tile resident
-// — the 8 ring slots are A hi (2), A lo (2), W hi (2), W lo (2) — and walks the six 32-MFMA products of the tile in an
-// order in which consecutive products share one register operand:
+// THREE TERMS. Streaming the three terms of a K-tile as three complete K-tiles costs 12 slot fills and 72 fragment reads per
+// 192 MFMAs of a wave, although A hi and W hi are each needed twice. This kernel keeps the four operand slabs of ONE K-tile
+// resident — the 8 ring slots are A hi (2), A lo (2), W hi (2), W lo (2) — and walks the six 32-MFMA products of the tile in
+// an order in which consecutive products share one register operand:
 //
 //     phase  product      fragments read (LDS)            slot refilled at the START of the phase (read last in the
 //                                                          phase before)                       wait for (next phase)
@@ -317,54 +319,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const T* __restrict__ A, c
 // give the two row halves different orders — a uniform order costs one repeated fragment read, Ah0 in P1 and P4.)
 // Every slot is single-buffered: it is refilled in the phase after its last read and needed again 5 phases later —
 // except A hi rows 0-63 (read in P1 and P4, refilled in P5, needed in P1: 2 phases).
+//
+// TWO TERMS: phases P1-P4 of the table are the whole K-tile (order hi.lo, hi.hi for every row, again the 128x128 kernel's).
+// 6 slot fills and 40 fragment reads per 128 MFMAs. A hi rows 0-63 is read in the first AND the last phase of a K-tile, so it
+// alternates between two slots by K-tile parity (slot 0 and the A lo slot 2, free in this form): the next K-tile's copy is
+// requested in P1 (4 phases of lead); W lo is refilled in P2, A hi rows 64-127 in P3, W hi in P4 (3 phases of lead each).
+//
 // Phase skeleton, barrier pairing of the two wave rows (half a phase apart) and the epilogue are those of gemm256_kernel:
 // a slot read in phase n may be overwritten from the start of phase n + 1 (the other row passed its opening barrier of
 // phase n, after its reads); data read in phase n + 1 is waited for (counted vmcnt) before the opening barrier of phase n.
-// vmcnt: a wave issues 16 fill instructions per K-tile in the order P1: 2, P2: 4, P3: 2, P4: 4, P5: 2, P6: 2; the number
-// of younger operations allowed at each wait is derived below. First K-tile of the stream and last K-tile of the stream
-// (different in-flight population) drain instead of counting.
+// vmcnt: a wave issues 16 fill instructions per K-tile in the order P1: 2, P2: 4, P3: 2, P4: 4, P5: 2, P6: 2 (two terms: 12 —
+// P1: 2, P2: 4, P3: 2, P4: 4); the number of younger operations allowed at each wait is derived below. First K-tile of the
+// stream and last K-tile of the stream (different in-flight population) drain instead of counting.
 // (dma16 / dma4, the LDS-DMA helpers every fill of this kernel goes through, live in common.h.)
+//
+// LO_OUT (16-bit epilogues): write the output's lo plane too. false when the consumer runs on two terms (fc1 -> fc2 in
+// FP16X3M): half the epilogue's stores, and the hi plane is bit-identical to the one the two-plane form writes.
+//
+// The fp32-output epilogue (bias [+ in-place residual] -> fp32) is hand-issued: residual loads and stores are inline asm on
+// ONE scalar base + a 32-bit lane offset, retired by counted vmcnt — four 16-row slabs of residual in flight per wave (the
+// registers are the main loop's dead operand fragments), stores never waited for —, every access a whole 128-byte line: the
+// slab goes through the wave's staging patch in two 32-column halves into the row-major lane mapping of the 16-bit epilogue
+// (8 rows x 128 B per instruction), the residual is loaded in that mapping directly. (DESIGN.md "fp32-output epilogue";
+// the two earlier forms — compiler-tracked loads / stores, and counted loads in the accumulator mapping — and the loop
+// ablation hooks of round 5 are in git history at 7f4ab81, their measurements in profiles/r05_gemm_lab_*.txt.)
 
 constexpr int X3_BIAS = 1;                                 // one 4-byte-per-lane DMA per wave per tile (its 64 bias values)
 constexpr int X3_LDS = P_LDS + 8 * 256;                    // + a 256-byte bias patch per wave
 
-// fp32-output epilogue form:
-//   0  straight from the accumulators with compiler-tracked loads / stores (rounds 3-4): the generated code is ONE chain per
-//      16-row slab — 4 residual loads, s_waitcnt vmcnt(0) (which also waits for the previous slab's stores to be
-//      acknowledged), 4 stores — i.e. 4 KiB in flight per wave: 20 us per 256x256 tile;
-//   1  the same lane -> element mapping, residual loads and stores through inline asm (scalar tile base + 32-bit lane
-//      offset), retired by counted vmcnt: the residual of FOUR slabs in flight per wave (16 KiB; the registers are the
-//      main loop's operand fragments, dead in the epilogue), stores never waited for;
-//   2  as 1, and every access a whole 128-byte line: the slab goes through the wave's staging patch (two halves of 32
-//      columns) into the row-major lane mapping of the 16-bit epilogue — 8 rows x 128 B per instruction instead of
-//      16 rows x 64 B —, the residual is loaded in that mapping directly.
-// The arithmetic per element is the same in all three: (oscale * acc + bias) + residual.
-#ifndef MNX_X3_EPI32
-#define MNX_X3_EPI32 2
-#endif
-// tools/gemm_lab ablations of the six-phase loop (results are garbage by design; what is timed is what remains):
-//   bit 0  no ring refills after the prologue            bit 1  no MFMAs (fragments still read)
-//   bit 2  no epilogue at all (accumulators zeroed)       bit 3  no fragment reads after the first K-tile
-//   bit 4  per-workgroup clock stamps (s_memtime = shader cycles, s_memrealtime = 100 MHz) -> x3_lab_stamps
-//   bit 5  epilogue arithmetic and LDS staging without its global loads / stores
-#ifndef MNX_X3_LAB
-#define MNX_X3_LAB 0
-#endif
-#if MNX_X3_LAB & 16
-__device__ unsigned long long x3_lab_stamps[256 * 8];
-#endif
-// tools/gemm_lab: cohorts of workgroups (cohort = (workgroup / 8) % 4, every XCD has all four) start MNX_X3_STAGGER x 10 ns
-// apart — are the tile epilogues of 256 workgroups in lockstep bound by what the chip can absorb at once?
-#ifndef MNX_X3_STAGGER
-#define MNX_X3_STAGGER 0
-#endif
 // Effective shader clock of the launches (measurement aid, always compiled): workgroup 0 adds its lifetime in shader cycles
 // (s_memtime) and in 100 MHz ticks (s_memrealtime) to two counters; x3_clock_read() turns them into MHz. The chip clocks to
 // its power budget — 1.65-1.9 GHz under this kernel with real operands, 2.39 GHz on zeros (profiles/r05_gemm_lab_ablations.txt)
 // — so a rate only means something next to the clock it was reached at. Cost: four scalar instructions per launch.
 __device__ unsigned long long x3_clk_acc[2];
 
-// fp32 epilogue forms 1 / 2: vector-memory operations younger than the residual loads of slab mt when they are waited for
+// fp32 epilogue: vector-memory operations younger than the residual loads of slab mt when they are waited for
 // (4 loads + 4 stores per slab, four slabs of loads in flight): 12 16 20 24 24 20 16 12
 __device__ __forceinline__ void x3_wait_younger(int mt) {
     const int y = mt < 4 ? 12 + 4 * mt : 12 + 4 * (7 - mt);
@@ -376,16 +365,18 @@ __device__ __forceinline__ void x3_wait_younger(int mt) {
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int TERMS, bool LO_OUT>
 __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A, const T* __restrict__ W, void* Cv,
                                                          const float* __restrict__ bias, const float* resid, int M, int N,
                                                          int K, int tiles_n, int n_tiles, const SplitArgs sp) {
+    static_assert(TERMS == 2 || TERMS == 3, "two or three product terms");
     typedef typename H16<T>::v8 v8;
     typedef typename H16<T>::v4 v4;
     constexpr bool OUT16 = (EPI == EPI_BIAS_16 || EPI == EPI_GELU_16);
-    // vector-memory operations of a tile's epilogue per wave: two 16-bit planes x 16 stores; fp32 output 32 stores
+    static_assert(OUT16 || LO_OUT, "LO_OUT only distinguishes the 16-bit epilogues");
+    // vector-memory operations of a tile's epilogue per wave: 16 stores per 16-bit plane; fp32 output 32 stores
     // (+ 32 residual loads)
-    constexpr int PST = OUT16 ? 2 * P_STORES : (EPI == EPI_RESID_F32 ? 64 : 32);
+    constexpr int PST = OUT16 ? (LO_OUT ? 2 : 1) * P_STORES : (EPI == EPI_RESID_F32 ? 64 : 32);
     T* C = (T*)Cv;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -398,12 +389,6 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     const int total_kt = my_tiles * nk;
     const long a_lo_b = (long)sp.a_lo * 2, w_lo_b = (long)sp.w_lo * 2;
     enum { S_AH0 = 0, S_AH1 = 1, S_AL0 = 2, S_AL1 = 3, S_WH0 = 4, S_WH1 = 5, S_WL0 = 6, S_WL1 = 7 };
-    constexpr bool LAB_NOFILL = (MNX_X3_LAB & 1) != 0, LAB_NOMFMA = (MNX_X3_LAB & 2) != 0, LAB_NOEPI = (MNX_X3_LAB & 4) != 0,
-                   LAB_NOREAD = (MNX_X3_LAB & 8) != 0, LAB_NOGLB = (MNX_X3_LAB & 32) != 0;
-#if MNX_X3_LAB & 16
-    unsigned long long lab_c0 = 0, lab_r0 = 0, lab_epi = 0;
-    if (lane == 0) { lab_c0 = __builtin_readcyclecounter(); lab_r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
 
     // DMA addressing: a wave fills two 1 KiB pieces (8 rows x 128 B) of every slot. The lane part of a piece's source
     // offset is the same for both 64-row halves of A (both 32-row halves of W): the half is a scalar addend on the base.
@@ -460,23 +445,18 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
 
     unsigned long long clk_c0 = 0, clk_r0 = 0;
     if (blockIdx.x == 0) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
-#if MNX_X3_STAGGER
-    {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * MNX_X3_STAGGER;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     int m0, n0;
     tile_origin(0, m0, n0);
     load_bias(n0);
     Pos cur = pos_at(0);
-    // prologue: everything K-tile 0 needs except A lo rows 64-127 (issued by its own P1), in the order of first use
+    // prologue: everything K-tile 0 needs in the order of first use (three terms: except A lo rows 64-127, issued by its own
+    // P1; A lo rows 0-63 last)
     fill_a(cur.a, 0, S_AH0); fill_w(cur.w + w_lo_b, S_WL0); fill_a(cur.a, 1, S_AH1); fill_w(cur.w, S_WH0);
-    fill_a(cur.a + a_lo_b, 0, S_AL0);
+    if (TERMS == 3) fill_a(cur.a + a_lo_b, 0, S_AL0);
     Pos nxt = cur;
     advance(nxt);
-    wait_vm<8>();                                 // bias, Ah0, W lo landed (Ah1 2 + W hi 4 + Al0 2 may fly)
+    if (TERMS == 3) wait_vm<8>();                 // bias, Ah0, W lo landed (Ah1 2 + W hi 4 + Al0 2 may fly)
+    else wait_vm<6>();                            // bias, Ah0, W lo landed (Ah1 2 + W hi 4 may fly)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row starts one segment late
 
@@ -491,13 +471,13 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
         a_rd[ks] = smem + lds_off256(wr * 64 + fr, ks * 4 + fg);
         w_rd[ks] = smem + S_WH0 * SLOT + lds_off256(wc * 32 + fr, ks * 4 + fg);
     }
-    auto read_a = [&](auto slot_c) {
-        constexpr int slot = decltype(slot_c)::value;
+    auto read_a_at = [&](int byte_off) {          // byte_off: slot * SLOT (an immediate when the slot is a constant)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const v8*)(a_rd[ks] + slot * SLOT + i * 2048);
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const v8*)(a_rd[ks] + byte_off + i * 2048);
     };
+    auto read_a = [&](auto slot_c) { read_a_at(decltype(slot_c)::value * SLOT); };
     auto read_w = [&](auto slot_c) {
         constexpr int rel = decltype(slot_c)::value - S_WH0;
 #pragma unroll
@@ -517,16 +497,6 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     // the 32 MFMAs of one phase: rows [mb*16, mb*16 + 64) of the wave tile += af . (b0 | b1)
     auto mfma_block = [&](auto mb_c) {
         constexpr int mb = decltype(mb_c)::value;
-        if (LAB_NOMFMA) {       // the fragments still have to arrive in registers
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[i][ks]));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b0[j][ks]), "v"(b1[j][ks]));
-            }
-            return;
-        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -543,64 +513,26 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
     using MB0 = std::integral_constant<int, 0>;
     using MB4 = std::integral_constant<int, 4>;
     auto epilogue = [&]() {
-        if (LAB_NOEPI) {
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    asm volatile("" ::"v"(acc[mt][nt]));
-                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-            return;
-        }
         f32x4 b4[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) b4[nt] = *(const f32x4*)(bias_s + nt * 16 + fg * 4);
         if (!OUT16) {
-#if MNX_X3_EPI32 == 0
-            // ---- fp32 output (+ in-place fp32 residual): straight from the accumulators. A lane owns 4 consecutive columns
-            // of row fr of every 16-row slab: 16-byte accesses, the 4 lane groups of a row cover 64 contiguous bytes. Every
-            // element is read and written by the same lane, so C may alias the residual. The loads and stores are ordinary
-            // (compiler-tracked) operations: its waits can only be stricter than needed here (they also drain the fills in
-            // flight, which are older), never too weak.
-            float* cp = (float*)Cv + (size_t)(m0 + wr * 128 + fr) * N + n0 + wc * 64 + fg * 4;
-            const float* rp = resid + (size_t)(m0 + wr * 128 + fr) * N + n0 + wc * 64 + fg * 4;
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                f32x4 v[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    v[nt] = acc[mt][nt] * sp.oscale + b4[nt];
-                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                if (EPI == EPI_RESID_F32 && !LAB_NOGLB) {
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) v[nt] += *(const f32x4*)(rp + (size_t)mt * 16 * N + nt * 16);
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    if (LAB_NOGLB) asm volatile("" ::"v"(v[nt]));
-                    else *(f32x4*)(cp + (size_t)mt * 16 * N + nt * 16) = v[nt];
-                }
-            }
-            return;
-#else
-            // ---- fp32 output (+ in-place fp32 residual), forms 1 / 2 (see MNX_X3_EPI32 above). Residual loads and stores are
-            // inline asm on a scalar base (the wave's 128 x 64 block of the tile) + a 32-bit lane offset; no compiler-tracked
-            // vector-memory operation exists in this epilogue, so the compiler adds no wait of its own. In-order retirement:
-            // the sequence of a wave is L0 L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 | S5 | S6 | S7 (L = 4 residual loads
-            // of a slab, S = its 4 stores); the residual of slab mt is complete once at most x3_epi_younger(mt) younger
-            // operations are outstanding. Every element is read and written by the same lane (C may alias the residual), and
-            // a slab's loads are issued after the stores of the slab four before it, whose rows they do not touch.
+            // ---- fp32 output (+ in-place fp32 residual). Residual loads and stores are inline asm on a scalar base (the wave's
+            // 128 x 64 block of the tile) + a 32-bit lane offset; no compiler-tracked vector-memory operation exists in this
+            // epilogue, so the compiler adds no wait of its own. In-order retirement: the sequence of a wave is
+            // L0 L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 | S5 | S6 | S7 (L = 4 residual loads of a slab, S = its 4 stores);
+            // the residual of slab mt is complete once at most x3_wait_younger(mt) younger operations are outstanding. Every
+            // element is read and written by the same lane (C may alias the residual), and a slab's loads are issued after the
+            // stores of the slab four before it, whose rows they do not touch.
             constexpr bool RES = (EPI == EPI_RESID_F32);
-            // ONE scalar base per array for the whole epilogue (the wave's 128 x 64 block of the tile); everything that changes
-            // from slab to slab is in the 32-bit lane offset (a VALU result: its hand-over to a vector-memory instruction is
-            // interlocked by the hardware). Reason: gfx950 requires wait states between a SALU write of an SGPR and a
-            // vector-memory instruction that uses it as its address base, and the compiler's hazard recognizer does not look
-            // into inline asm — the first build of this epilogue re-derived the base per slab with s_add / s_addc right in
-            // front of the asm stores and 1.4 % of the words landed elsewhere. The s_nop below covers the one place where the
-            // bases are produced. The stores carry their own s_nop: a VALU write of the data registers of a 16-byte store in
-            // the very next instruction is the other hazard the compiler cannot see (0.2 % wrong words in the bias-only form).
+            // ONE scalar base per array for the whole epilogue; everything that changes from slab to slab is in the 32-bit lane
+            // offset (a VALU result: its hand-over to a vector-memory instruction is interlocked by the hardware). Reason:
+            // gfx950 requires wait states between a SALU write of an SGPR and a vector-memory instruction that uses it as its
+            // address base, and the compiler's hazard recognizer does not look into inline asm — the first build of this
+            // epilogue re-derived the base per slab with s_add / s_addc right in front of the asm stores and 1.4 % of the words
+            // landed elsewhere. The s_nop below covers the one place where the bases are produced. The stores carry their own
+            // s_nop: a VALU write of the data registers of a 16-byte store in the very next instruction is the other hazard
+            // the compiler cannot see (0.2 % wrong words in the bias-only form). tests/test_device_math.py pins both in the ISA.
             const size_t wbase = ((size_t)(m0 + wr * 128) * N + n0 + wc * 64) * 4;
             const char* cb = (const char*)Cv + wbase;
             const char* rb = RES ? (const char*)resid + wbase : cb;
@@ -608,19 +540,6 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
             const unsigned slab_b = (unsigned)N * 64u;                // 16 rows
 #define MNX_X3_LD1(dst, off, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=&v"(dst) : "v"(off), "s"(rb) : "memory")
 #define MNX_X3_ST1(src, off, imm) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm "\n\ts_nop 1" ::"v"(off), "v"(src), "s"(cb) : "memory")
-#if MNX_X3_EPI32 == 1
-            const unsigned voff = (unsigned)((fr * N + fg * 4) * 4);          // row fr, 16 bytes at column 4 fg (+ 16 nt)
-#define MNX_X3_LD(d, mt)                                                                                                  \
-    do {                                                                                                                  \
-        const unsigned o_ = voff + (unsigned)(mt) * slab_b;                                                               \
-        MNX_X3_LD1(d[0], o_, 0); MNX_X3_LD1(d[1], o_, 64); MNX_X3_LD1(d[2], o_, 128); MNX_X3_LD1(d[3], o_, 192);         \
-    } while (0)
-#define MNX_X3_ST(v, mt)                                                                                                  \
-    do {                                                                                                                  \
-        const unsigned o_ = voff + (unsigned)(mt) * slab_b;                                                               \
-        MNX_X3_ST1(v[0], o_, 0); MNX_X3_ST1(v[1], o_, 64); MNX_X3_ST1(v[2], o_, 128); MNX_X3_ST1(v[3], o_, 192);         \
-    } while (0)
-#else
             // row-major mapping: lane l <-> row (l >> 3) (+ 8 for the second access), 16 bytes at column 4 (l & 7) of a
             // 32-column half: d[2 h + i] = rows 8 i .. 8 i + 7 of half h
             const unsigned voff = (unsigned)((((lane >> 3)) * N + (lane & 7) * 4) * 4);
@@ -635,9 +554,8 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
         const unsigned o_ = voff + (unsigned)(mt) * slab_b, o8_ = o_ + half_b;                                            \
         MNX_X3_ST1(v[0], o_, 0); MNX_X3_ST1(v[1], o8_, 0); MNX_X3_ST1(v[2], o_, 128); MNX_X3_ST1(v[3], o8_, 128);        \
     } while (0)
-#endif
             f32x4 r[4][4];
-            if (RES && !LAB_NOGLB) {
+            if (RES) {
                 MNX_X3_LD(r[0], 0); MNX_X3_LD(r[1], 1); MNX_X3_LD(r[2], 2); MNX_X3_LD(r[3], 3);
             }
 #pragma unroll
@@ -648,7 +566,6 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
                     v[nt] = acc[mt][nt] * sp.oscale + b4[nt];
                     acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-#if MNX_X3_EPI32 == 2
                 // accumulator mapping -> row-major mapping through the wave's staging patch, one 32-column half at a time
                 // (16 rows x 128 B = the 2 KiB patch; a wave's LDS operations execute in order)
                 f32x4 t[4];
@@ -664,8 +581,7 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = t[q];
-#endif
-                if (RES && !LAB_NOGLB) {
+                if (RES) {
                     x3_wait_younger(mt);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -673,22 +589,16 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
                         v[q] += r[mt & 3][q];
                     }
                 }
-                if (LAB_NOGLB) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(v[q]));
-                } else {
-                    MNX_X3_ST(v, mt);
-                    if (RES && mt + 4 < 8) MNX_X3_LD(r[mt & 3], mt + 4);
-                }
+                MNX_X3_ST(v, mt);
+                if (RES && mt + 4 < 8) MNX_X3_LD(r[mt & 3], mt + 4);
             }
 #undef MNX_X3_LD
 #undef MNX_X3_ST
 #undef MNX_X3_LD1
 #undef MNX_X3_ST1
             return;
-#endif
         }
-        // ---- 16-bit output: 16-row slabs through the wave's own staging patch, hi plane then lo plane ----
+        // ---- 16-bit output: 16-row slabs through the wave's own staging patch, hi plane then (LO_OUT) lo plane ----
         T* crow = C + (size_t)(m0 + wr * 128 + (lane >> 3)) * N + n0 + wc * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
@@ -698,7 +608,7 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
                 f32x4 v = acc[mt][nt] * sp.oscale + b4[nt];
                 if (EPI == EPI_GELU_16) v = gelu_split4(v);
                 v4 hi;
-                split16x4<T>(v, hi, lo[nt]);
+                split16x4<T>(v, hi, lo[nt]);        // (LO_OUT false: the lo half is dead code; hi is derived the same way)
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = hi;
             }
@@ -706,18 +616,18 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
             for (int i = 0; i < 2; ++i) {
                 const int row = (lane >> 3) + 8 * i;
                 const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-                if (LAB_NOGLB) asm volatile("" ::"v"(o8));
-                else *(v8*)(crow + (size_t)(mt * 16 + 8 * i) * N) = o8;
+                *(v8*)(crow + (size_t)(mt * 16 + 8 * i) * N) = o8;
             }
+            if (LO_OUT) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = lo[nt];
+                for (int nt = 0; nt < 4; ++nt)
+                    *(v4*)(stg + fr * 128 + (((nt * 2 + (fg >> 1)) ^ (fr & 7)) << 4) + (fg & 1) * 8) = lo[nt];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = (lane >> 3) + 8 * i;
-                const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-                if (LAB_NOGLB) asm volatile("" ::"v"(o8));
-                else *(v8*)(crow + sp.c_lo + (size_t)(mt * 16 + 8 * i) * N) = o8;
+                for (int i = 0; i < 2; ++i) {
+                    const int row = (lane >> 3) + 8 * i;
+                    const v8 o8 = *(const v8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                    *(v8*)(crow + sp.c_lo + (size_t)(mt * 16 + 8 * i) * N) = o8;
+                }
             }
         }
     };
@@ -739,60 +649,85 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
         const bool has_next = g + 1 < total_kt;
         const bool first_kt = (kt == 0 && seq > 0);
         const bool drain = (g == 0) || !has_next;
-        // ---- P1: Ah0 . Wl -> rows 0..63.   refill: A lo rows 64-127 of THIS K-tile (its slot was read last in P6)
-        const bool rd = !LAB_NOREAD || g == 0;
-        if (!LAB_NOFILL || g == 0) fill_a(cur.a + a_lo_b, 1, S_AL1);
-        if (first_kt) load_bias(n0);
-        if (rd) { read_a(R_AH0{}); read_w(R_WL{}); }
-        // Ah1 (issued in P3 of the previous K-tile). Younger: P4 4, P5 2, P6 2 [, PST stores], this phase's 2 [+ bias]
-        MNX_X3_WAIT(10, PST + X3_BIAS);
-        mfma_block(MB0{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P2: Ah1 . Wl -> rows 64..127.   refill: W lo of the next K-tile
-        if (has_next && !LAB_NOFILL) fill_w(nxt.w + w_lo_b, S_WL0);
-        if (rd) read_a(R_AH1{});
-        // W hi (issued in P4 of the previous K-tile). Younger: P5 2, P6 2 [, PST stores], P1 2 [+ bias], P2 4
-        MNX_X3_WAIT(10, PST + X3_BIAS);
-        mfma_block(MB4{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P3: Ah1 . Wh -> rows 64..127.   refill: A hi rows 64-127 of the next K-tile.   P4 re-reads Ah0: landed before P1
-        if (has_next && !LAB_NOFILL) fill_a(nxt.a, 1, S_AH1);
-        if (rd) read_w(R_WH{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mfma_block(MB4{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P4: Ah0 . Wh -> rows 0..63.   refill: W hi of the next K-tile (its fragments stay in registers until P6)
-        if (has_next && !LAB_NOFILL) fill_w(nxt.w, S_WH0);
-        if (rd) read_a(R_AH0{});
-        // Al0 (issued in P6 of the previous K-tile, before its epilogue). Younger: [PST stores,] P1 2 [+ bias], P2 4, P3 2, P4 4
-        MNX_X3_WAIT(12, PST + X3_BIAS);
-        mfma_block(MB0{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P5: Al0 . Wh -> rows 0..63.   refill: A hi rows 0-63 of the next K-tile
-        if (has_next && !LAB_NOFILL) fill_a(nxt.a, 0, S_AH0);
-        if (rd) read_a(R_AL0{});
-        // Al1 (issued in P1 of this K-tile, before the bias DMA). Younger: [bias,] P2 4, P3 2, P4 4, P5 2
-        MNX_X3_WAIT(12, X3_BIAS);
-        mfma_block(MB0{});
-        __builtin_amdgcn_s_barrier();
-        // ---- P6: Al1 . Wh -> rows 64..127.   refill: A lo rows 0-63 of the next K-tile
-        if (has_next && !LAB_NOFILL) fill_a(nxt.a + a_lo_b, 0, S_AL0);
-        if (rd) read_a(R_AL1{});
-        // Ah0', Wl' of the next K-tile (issued in P5 / P2). Younger than Ah0': this phase's 2
-        MNX_X3_WAIT(2, 0);
-        mfma_block(MB4{});
+        if constexpr (TERMS == 3) {
+            // ---- P1: Ah0 . Wl -> rows 0..63.   refill: A lo rows 64-127 of THIS K-tile (its slot was read last in P6)
+            fill_a(cur.a + a_lo_b, 1, S_AL1);
+            if (first_kt) load_bias(n0);
+            read_a(R_AH0{}); read_w(R_WL{});
+            // Ah1 (issued in P3 of the previous K-tile). Younger: P4 4, P5 2, P6 2 [, PST stores], this phase's 2 [+ bias]
+            MNX_X3_WAIT(10, PST + X3_BIAS);
+            mfma_block(MB0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P2: Ah1 . Wl -> rows 64..127.   refill: W lo of the next K-tile
+            if (has_next) fill_w(nxt.w + w_lo_b, S_WL0);
+            read_a(R_AH1{});
+            // W hi (issued in P4 of the previous K-tile). Younger: P5 2, P6 2 [, PST stores], P1 2 [+ bias], P2 4
+            MNX_X3_WAIT(10, PST + X3_BIAS);
+            mfma_block(MB4{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P3: Ah1 . Wh -> rows 64..127.   refill: A hi rows 64-127 of the next K-tile.   P4 re-reads Ah0: landed before P1
+            if (has_next) fill_a(nxt.a, 1, S_AH1);
+            read_w(R_WH{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfma_block(MB4{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P4: Ah0 . Wh -> rows 0..63.   refill: W hi of the next K-tile (its fragments stay in registers until P6)
+            if (has_next) fill_w(nxt.w, S_WH0);
+            read_a(R_AH0{});
+            // Al0 (issued in P6 of the previous K-tile, before its epilogue). Younger: [PST stores,] P1 2 [+ bias], P2 4, P3 2, P4 4
+            MNX_X3_WAIT(12, PST + X3_BIAS);
+            mfma_block(MB0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P5: Al0 . Wh -> rows 0..63.   refill: A hi rows 0-63 of the next K-tile
+            if (has_next) fill_a(nxt.a, 0, S_AH0);
+            read_a(R_AL0{});
+            // Al1 (issued in P1 of this K-tile, before the bias DMA). Younger: [bias,] P2 4, P3 2, P4 4, P5 2
+            MNX_X3_WAIT(12, X3_BIAS);
+            mfma_block(MB0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P6: Al1 . Wh -> rows 64..127.   refill: A lo rows 0-63 of the next K-tile
+            if (has_next) fill_a(nxt.a + a_lo_b, 0, S_AL0);
+            read_a(R_AL1{});
+            // Ah0', Wl' of the next K-tile (issued in P5 / P2). Younger than Ah0': this phase's 2
+            MNX_X3_WAIT(2, 0);
+            mfma_block(MB4{});
+        } else {
+            // A hi rows 0-63 of this K-tile: slot 0 (even K-tiles of the stream) or slot 2 (odd); the next K-tile's goes to the other
+            const int ah0_cur = (g & 1) ? S_AL0 : S_AH0, ah0_nxt = (g & 1) ? S_AH0 : S_AL0;
+            // ---- P1: Ah0 . Wl -> rows 0..63.   refill: A hi rows 0-63 of the NEXT K-tile (its slot was read last in P4 of the previous one)
+            if (has_next) fill_a(nxt.a, 0, ah0_nxt);
+            if (first_kt) load_bias(n0);
+            read_a_at(ah0_cur * SLOT); read_w(R_WL{});
+            // Ah1 (issued in P3 of the previous K-tile). Younger: P4 4 [, PST stores], this phase's 2 [+ bias]
+            MNX_X3_WAIT(6, PST + X3_BIAS);
+            mfma_block(MB0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P2: Ah1 . Wl -> rows 64..127.   refill: W lo of the next K-tile
+            if (has_next) fill_w(nxt.w + w_lo_b, S_WL0);
+            read_a(R_AH1{});
+            // W hi (issued in P4 of the previous K-tile). Younger: [PST stores,] P1 2 [+ bias], P2 4
+            MNX_X3_WAIT(6, PST + X3_BIAS);
+            mfma_block(MB4{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P3: Ah1 . Wh -> rows 64..127.   refill: A hi rows 64-127 of the next K-tile.   P4 re-reads Ah0: landed before P1
+            if (has_next) fill_a(nxt.a, 1, S_AH1);
+            read_w(R_WH{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfma_block(MB4{});
+            __builtin_amdgcn_s_barrier();
+            // ---- P4: Ah0 . Wh -> rows 0..63.   refill: W hi of the next K-tile
+            if (has_next) fill_w(nxt.w, S_WH0);
+            read_a_at(ah0_cur * SLOT);
+            // Ah0', Wl' of the next K-tile (issued in P1 — before the bias DMA — and P2). Younger than Wl': P3 2, P4 4
+            MNX_X3_WAIT(6, 0);
+            mfma_block(MB0{});
+        }
         // epilogue placement as gemm256_kernel: second wave row before its closing barrier, first row after its own
-#if MNX_X3_LAB & 16
-        unsigned long long lab_e0 = 0;
-        if (last_kt) lab_e0 = __builtin_amdgcn_s_memrealtime();
-#endif
         if (last_kt && wr == 1) epilogue();
         __builtin_amdgcn_s_barrier();
         if (last_kt && wr == 0) epilogue();
-#if MNX_X3_LAB & 16
-        if (last_kt) lab_epi += __builtin_amdgcn_s_memrealtime() - lab_e0;     // tile end -> this wave is through its epilogue code
-#endif
         cur = nxt;
         advance(nxt);
         if (last_kt) {
@@ -808,15 +743,6 @@ __global__ __launch_bounds__(512) void gemm256x3_kernel(const T* __restrict__ A,
         atomicAdd(&x3_clk_acc[0], (unsigned long long)__builtin_readcyclecounter() - clk_c0);
         atomicAdd(&x3_clk_acc[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0);
     }
-#if MNX_X3_LAB & 16
-    if (lane == 0 && (wave == 0 || wave == 4)) {
-        unsigned long long* o = x3_lab_stamps + blockIdx.x * 8 + (wave >> 2) * 4;
-        o[0] = __builtin_readcyclecounter() - lab_c0;
-        o[1] = __builtin_amdgcn_s_memrealtime() - lab_r0;
-        o[2] = lab_epi;
-        o[3] = (unsigned long long)my_tiles;
-    }
-#endif
 }
 
 }  // namespace
@@ -850,32 +776,53 @@ bool gemm256x3_supports(int dtype, int epi, int M, int N, int K) {
     return M > 0 && M % TM == 0 && N % TN == 0 && K % TK == 0 && K >= 2 * TK;
 }
 
+// Instantiated forms: three terms with both output planes (every split layer of FP16X3 / BF16X3), and for fp16 the forms
+// FP16X3M needs — two terms (any epilogue) and a GELU output that keeps the hi plane only (fc1 when fc2 runs on two terms;
+// the bias epilogue — qkv — always feeds the three-term attention).
+// bf16 operands never run on two terms (a bf16 hi plane alone is the plain bf16 mode).
 hipError_t launch_gemm256x3(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                             const float* resid, int M, int N, int K, hipStream_t s, const SplitArgs* sp) {
-    if (!sp || sp->terms != 3 || !gemm256x3_supports(dtype, epi, M, N, K)) return hipErrorInvalidValue;
+    if (!sp || (sp->terms != 3 && sp->terms != 2) || !gemm256x3_supports(dtype, epi, M, N, K)) return hipErrorInvalidValue;
     if (epi == EPI_RESID_F32 && !resid) return hipErrorInvalidValue;
     if (!bias) return hipErrorInvalidValue;     // callers without a bias pass a zero vector (the engine keeps one)
+    const bool out16 = (epi == EPI_BIAS_16 || epi == EPI_GELU_16);
+    if (sp->c_planes != 1 && sp->c_planes != 2) return hipErrorInvalidValue;
+    const bool lo_out = !out16 || sp->c_planes == 2;
+    if (dtype != MNX_DT_F16X3 && (sp->terms != 3 || !lo_out)) return hipErrorInvalidValue;
     const SplitArgs spv = *sp;
     const int tm = M / TM, tn = N / TN;
     const int cus = persistent_cus();
     const int grid = tm * tn < cus ? tm * tn : cus;
-#define MNX_G256X3_CASE(TT, E)                                                                                            \
-    case E: {                                                                                                             \
-        const hipError_t attr = lds_opt_in<gemm256x3_kernel<TT, E>>(X3_LDS);                                                 \
+#define MNX_G256X3_GO(TT, E, TERMS, LO)                                                                                    \
+    do {                                                                                                                  \
+        const hipError_t attr = lds_opt_in<gemm256x3_kernel<TT, E, TERMS, LO>>(X3_LDS);                                     \
         if (attr != hipSuccess) return attr;                                                                              \
-        hipLaunchKernelGGL((gemm256x3_kernel<TT, E>), dim3(grid), dim3(512), X3_LDS, s, (const TT*)A, (const TT*)W, C,    \
-                           bias, resid, M, N, K, tn, tm * tn, spv);                                                       \
-        break;                                                                                                            \
+        hipLaunchKernelGGL((gemm256x3_kernel<TT, E, TERMS, LO>), dim3(grid), dim3(512), X3_LDS, s, (const TT*)A,          \
+                           (const TT*)W, C, bias, resid, M, N, K, tn, tm * tn, spv);                                      \
+    } while (0)
+    if (dtype == MNX_DT_BF16X3) {
+        switch (epi) {
+            case EPI_BIAS_16: MNX_G256X3_GO(bf16_t, EPI_BIAS_16, 3, true); break;
+            case EPI_GELU_16: MNX_G256X3_GO(bf16_t, EPI_GELU_16, 3, true); break;
+            case EPI_RESID_F32: MNX_G256X3_GO(bf16_t, EPI_RESID_F32, 3, true); break;
+            default: MNX_G256X3_GO(bf16_t, EPI_BIAS_F32, 3, true); break;
+        }
+    } else if (spv.terms == 3) {
+        switch (epi) {
+            case EPI_BIAS_16: if (!lo_out) return hipErrorInvalidValue; MNX_G256X3_GO(f16_t, EPI_BIAS_16, 3, true); break;
+            case EPI_GELU_16: if (lo_out) MNX_G256X3_GO(f16_t, EPI_GELU_16, 3, true); else MNX_G256X3_GO(f16_t, EPI_GELU_16, 3, false); break;
+            case EPI_RESID_F32: MNX_G256X3_GO(f16_t, EPI_RESID_F32, 3, true); break;
+            default: MNX_G256X3_GO(f16_t, EPI_BIAS_F32, 3, true); break;
+        }
+    } else {
+        switch (epi) {
+            case EPI_BIAS_16: if (!lo_out) return hipErrorInvalidValue; MNX_G256X3_GO(f16_t, EPI_BIAS_16, 2, true); break;
+            case EPI_GELU_16: if (lo_out) MNX_G256X3_GO(f16_t, EPI_GELU_16, 2, true); else MNX_G256X3_GO(f16_t, EPI_GELU_16, 2, false); break;
+            case EPI_RESID_F32: MNX_G256X3_GO(f16_t, EPI_RESID_F32, 2, true); break;
+            default: MNX_G256X3_GO(f16_t, EPI_BIAS_F32, 2, true); break;
+        }
     }
-#define MNX_G256X3_TYPE(TT)                                                                                               \
-    switch (epi) {                                                                                                        \
-        MNX_G256X3_CASE(TT, EPI_BIAS_16) MNX_G256X3_CASE(TT, EPI_GELU_16) MNX_G256X3_CASE(TT, EPI_RESID_F32)              \
-        MNX_G256X3_CASE(TT, EPI_BIAS_F32)                                                                                 \
-        default: return hipErrorInvalidValue;                                                                             \
-    }
-    if (dtype == MNX_DT_F16X3) { MNX_G256X3_TYPE(f16_t) } else { MNX_G256X3_TYPE(bf16_t) }
-#undef MNX_G256X3_TYPE
-#undef MNX_G256X3_CASE
+#undef MNX_G256X3_GO
     return hipGetLastError();
 }
 
@@ -948,12 +895,6 @@ hipError_t mfma_probe(int iters, hipStream_t s, double* tflops, double* mhz) {
     return hipSuccess;
 }
 
-#if MNX_X3_LAB & 16
-hipError_t x3_lab_read_stamps(unsigned long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(x3_lab_stamps), sizeof(unsigned long long) * 256 * 8);
-}
-#endif
-
 bool gemm256_supports(int dtype, int epi, int M, int N, int K) {
     if (dtype != MNX_DT_BF16 && dtype != MNX_DT_F16 && !dt_split(dtype)) return false;
     if (epi != EPI_BIAS_16 && epi != EPI_GELU_16) return false;
@@ -968,9 +909,9 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
                           int K, hipStream_t s, const SplitArgs* sp) {
     if (!bias || M % TM || N % TN || K % TK || K < 2 * TK) return hipErrorInvalidValue;
     const bool split = dt_split(dtype);
-    if (split && (!sp || (sp->terms != 1 && sp->terms != 3))) return hipErrorInvalidValue;
+    if (split && (!sp || sp->terms < 1 || sp->terms > 3)) return hipErrorInvalidValue;
     const SplitArgs spv = split ? *sp : SplitArgs();
-    if (split && spv.terms == 3)        // all three terms: the shared-fill six-phase kernel
+    if (split && spv.terms >= 2)        // three / two terms: the shared-fill six- / four-phase kernel
         return launch_gemm256x3(dtype, epi, A, W, C, bias, nullptr, M, N, K, s, sp);
     const int tm = M / TM, tn = N / TN;
     const int grid = tm * tn < 256 ? tm * tn : 256;
@@ -995,3 +936,4 @@ hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void
 }
 
 }  // namespace mnx
+

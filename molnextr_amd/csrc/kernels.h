@@ -20,12 +20,16 @@ enum { EPI_BIAS_16 = 0, EPI_GELU_16 = 1, EPI_RESID_F32 = 2, EPI_BIAS_F32 = 3 };
 // Split-operand GEMM arguments (dtype BF16X3 / F16X3). *_lo = ELEMENT offset of an operand's lo plane from its hi plane
 // (the pointer passed as A / W / C); C = epi(oscale * acc + bias): the weights of the fp16 split are stored scaled by a
 // power of two per matrix (their lo plane would otherwise be subnormal), oscale undoes it exactly.
-// terms: 3 = hi.hi + hi.lo + lo.hi; 1 = hi.hi only (error-budget aid: the layer runs as the plain 16-bit mode would,
-// but still writes both output planes).
+// terms: 3 = ah.wh + ah.wl + al.wh; 2 = ah.wh + ah.wl (the ACTIVATION's lo plane is neither read nor multiplied — a_lo is
+// ignored —, the weight keeps both: the weight's rounding is systematic, the activation's is noise; compute_dtype FP16X3M,
+// DESIGN.md section 4.3); 1 = ah.wh only (error-budget aid: the layer runs as the plain 16-bit mode would).
+// c_planes (16-bit-output epilogues): 2 = hi and lo output planes; 1 = the hi plane only (c_lo ignored) — for a consumer
+// that runs on two terms. The hi plane is the same bits either way.
 struct SplitArgs {
     size_t a_lo = 0, w_lo = 0, c_lo = 0;
     float oscale = 1.f;
     int terms = 3;
+    int c_planes = 2;
 };
 
 // ---- gemm.hip -------------------------------------------------------------------------------
@@ -44,7 +48,7 @@ hipError_t launch_gemm16_tile128(int dtype, int epi, const void* A, const void* 
 bool gemm256_supports(int dtype, int epi, int M, int N, int K);   // shape / epilogue fit AND the tile count fills 256 CUs
 hipError_t launch_gemm256(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N,
                           int K, hipStream_t s, const SplitArgs* sp = nullptr);
-// gemm256x3_kernel (gemm256.hip): split dtypes with all three terms, any epilogue, M and N multiples of 256. Runs EVERY
+// gemm256x3_kernel (gemm256.hip): split dtypes with three (or, fp16 only, two) terms, any epilogue, M and N multiples of 256. Runs EVERY
 // tile it is given on one workgroup per CU in rounds of 256: launch_gemm16 hands it whole rounds and the 128x128 kernel
 // the remaining rows.
 bool gemm256x3_supports(int dtype, int epi, int M, int N, int K);
@@ -70,11 +74,13 @@ hipError_t launch_patch_embed(const float* img, const float* w_t /*[48][C]*/, co
                               const float* beta, float* x, int B, int S, int C, hipStream_t s);
 // y16[M,C] = LayerNorm(x[M,C]) (eps) as 16-bit; optionally also fp32 copy y32. Split dtypes: y16 = hi plane, the lo plane
 // is written y_lo ELEMENTS behind it. nonfinite_flag (device int, may be null): set to 1 when a row's result is not finite.
+// Split dtypes with planes == 1: only the hi plane is written (the consumer runs on two terms), y_lo is ignored.
 hipError_t launch_layernorm16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, float* y32,
-                              int M, int C, float eps, hipStream_t s, size_t y_lo = 0, int* nonfinite_flag = nullptr);
+                              int M, int C, float eps, hipStream_t s, size_t y_lo = 0, int* nonfinite_flag = nullptr,
+                              int planes = 2);
 // patch-merging gather + LayerNorm(4C): x [B,H,W,C] fp32 -> y16 [B,(H/2)(W/2),4C]
 hipError_t launch_merge_ln16(int dtype, const float* x, const float* gamma, const float* beta, void* y16, int B, int H,
-                             int W, int C, float eps, hipStream_t s, size_t y_lo = 0);
+                             int W, int C, float eps, hipStream_t s, size_t y_lo = 0, int planes = 2);
 // window attention: qkv16 [B*H*W, 3C] -> out16 [B*H*W, C] (original token order); table [529, heads] fp32.
 // Split dtypes: qkv_lo / out_lo = element offsets of the lo planes; terms as SplitArgs::terms.
 hipError_t launch_window_attn(int dtype, const void* qkv16, const float* rel_table, void* out16, int B, int H, int W,

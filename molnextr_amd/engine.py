@@ -18,18 +18,22 @@ from . import weights as W
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmolnextr_hip.so")
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mnx_workspace_bytes", "mnx_encode",
            "mnx_set_encoder_tap", "mnx_decode_greedy", "mnx_edges", "mnx_gemm16", "mnx_profile_enable",
            "mnx_profile_read", "mnx_set_token_classes", "mnx_predict", "mnx_atom_scan", "mnx_decode_beam", "mnx_preprocess",
            "mnx_probe_decode_attn", "mnx_predict_beam", "mnx_set_split_terms", "mnx_encoder_status",
-           "mnx_gemm16_split", "mnx_decode_forced", "mnx_gemm_clock", "mnx_probe_mfma")
+           "mnx_gemm16_split", "mnx_decode_forced", "mnx_gemm_clock", "mnx_probe_mfma", "mnx_set_op_terms")
 
 # Encoder operand modes (include/molnextr_hip.h MNX_DTYPE_*). "fp16x3" — split fp16 operands, three MFMA terms per
 # product, fp32-class results — is the default: it is the fastest mode whose tokens / atoms / bonds equal the reference's.
-DTYPES = {"bf16": 0, "fp16": 1, "fp32": 2, "bf16x3": 3, "fp16x3": 4}
+# "fp16x3m" is fp16x3 with the op classes of FP16X3M_TWO_TERM (fc1, fc2: 64 % of the encoder's GEMM time) on TWO terms —
+# the activation's lo plane dropped, the weight's kept: log-probs within 5e-4 of the reference's (north_star allows 1e-3),
+# tokens / atoms / bonds still exact on both fixture checkpoints (tests/test_gpu_pixels.py).
+DTYPES = {"bf16": 0, "fp16": 1, "fp32": 2, "bf16x3": 3, "fp16x3": 4, "fp16x3m": 5}
 DEFAULT_DTYPE = "fp16x3"
 SPLIT_CLASSES = {"qkv": 1, "attn": 2, "proj": 4, "fc1": 8, "fc2": 16, "merge": 32}
+FP16X3M_TWO_TERM = ("fc1", "fc2")       # include/molnextr_hip.h MNX_FP16X3M_TWO_TERM_BY_STAGE (tags: "cls" or "cls.sN", N 0-based)
 
 
 class MnxConfig(C.Structure):
@@ -46,7 +50,7 @@ class MnxWeightDesc(C.Structure):
 
 
 MNX_ERR_RANGE = -6      # include/molnextr_hip.h: the encoder produced non-finite features (fp16 operand range)
-RANGE_FALLBACK = {"fp16x3": "bf16x3", "fp16": "bf16"}    # the same operand structure with the fp32 exponent range
+RANGE_FALLBACK = {"fp16x3": "bf16x3", "fp16x3m": "bf16x3", "fp16": "bf16"}    # the same operand structure with the fp32 exponent range
 
 
 class MnxError(RuntimeError):
@@ -94,6 +98,8 @@ def load_library():
     lib.mnx_set_encoder_tap.argtypes = [vp, i32, vp]
     lib.mnx_set_split_terms.restype = C.c_int
     lib.mnx_set_split_terms.argtypes = [vp, i32]
+    lib.mnx_set_op_terms.restype = C.c_int
+    lib.mnx_set_op_terms.argtypes = [vp, i32, i32]
     lib.mnx_encoder_status.restype = C.c_int
     lib.mnx_encoder_status.argtypes = [vp, C.POINTER(i32), vp]
     lib.mnx_decode_greedy.restype = C.c_int
@@ -243,10 +249,26 @@ class Engine:
         self._check(self.lib.mnx_set_encoder_tap(self.h, item, _ptr(dst)), "mnx_set_encoder_tap")
 
     def set_split_terms(self, three_term_classes=None):
-        """Split modes only (test aid): the op classes (names of SPLIT_CLASSES) evaluated with all three product terms;
-        the others run hi.hi alone, as the plain 16-bit mode would. None = all classes (the default)."""
+        """Split modes only (test aid): the op classes (names of SPLIT_CLASSES) evaluated with their full term count (three,
+        or two for the classes of set_op_terms); the others run hi.hi alone, as the plain 16-bit mode would. None = all
+        classes (the default)."""
         mask = 63 if three_term_classes is None else sum(SPLIT_CLASSES[c] for c in three_term_classes)
         self._check(self.lib.mnx_set_split_terms(self.h, mask), "mnx_set_split_terms")
+
+    def set_op_terms(self, two_term=None):
+        """fp16x3 / fp16x3m engines: the Linear op classes that run on TWO product terms (ah.wh + ah.wl), as tags "cls" (every
+        stage) or "cls.sN" (encoder stage N, 0-based) with cls a name of SPLIT_CLASSES other than 'attn' — the syntax of
+        tools/study_split_terms.py --two. None = the mode's own table (fp16x3: none, fp16x3m: FP16X3M_TWO_TERM)."""
+        if two_term is None:
+            two_term = FP16X3M_TWO_TERM if self.dtype == "fp16x3m" else ()
+        n = len(self.enc.depths)
+        masks = [0] * n
+        for tag in two_term:
+            cls, _, st = tag.partition(".s")
+            for i in ([int(st)] if st else range(n)):
+                masks[i] |= SPLIT_CLASSES[cls]
+        for i, m in enumerate(masks):
+            self._check(self.lib.mnx_set_op_terms(self.h, i, m), "mnx_set_op_terms")
 
     def encoder_nonfinite(self) -> bool:
         """Synchronises and reports (then clears) whether an encode since the last call produced non-finite features
@@ -443,11 +465,12 @@ class Engine:
 
     def gemm16_split(self, epi: int, A2: torch.Tensor, W2: torch.Tensor, Cout: torch.Tensor,
                      bias: Optional[torch.Tensor], oscale: float = 1.0, terms: int = 3):
-        """Split-mode GEMM on caller buffers: A2 [2,M,K] and W2 [2,N,K] hold the hi / lo planes (16-bit); Cout is
-        [2,M,N] 16-bit (epi 0, 1) or [M,N] fp32 (epi 2: bias + residual in place, 3: bias)."""
+        """Split-mode GEMM on caller buffers: A2 [2,M,K] (terms = 2: [1,M,K] will do, the lo plane is not read) and W2 [2,N,K]
+        hold the hi / lo planes (16-bit); Cout is [2,M,N] 16-bit (epi 0, 1; with epi | 0x400 [1,M,N]: hi plane only) or
+        [M,N] fp32 (epi 2: bias + residual in place, 3: bias). epi | 0x200: the 128x128 kernel whatever the dispatch."""
         _, M, K = A2.shape
         N = W2.shape[1]
-        c_lo = M * N if Cout.dim() == 3 else 0
+        c_lo = M * N if Cout.dim() == 3 and Cout.shape[0] == 2 else 0
         self._check(self.lib.mnx_gemm16_split(self.h, epi, _ptr(A2), M * K, _ptr(W2), N * K, float(oscale), _ptr(Cout), c_lo,
                                               _ptr(bias), M, N, K, terms, _stream()), "mnx_gemm16_split")
         return Cout

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import weights as W
-from .engine import Engine, MnxError
+from .engine import DEFAULT_DTYPE, Engine, MnxError
 from .preprocess import load_image_rgb, transform_image
 from .tokenizer import get_tokenizer
 
@@ -132,11 +132,13 @@ class molnextr:
     the literal 'synthetic' opts into the deterministic hash-generated checkpoint (tests / bench only: its predictions
     are meaningless as chemistry). There is no default: like the reference, the model cannot run without weights.
     device: torch.device('cuda', i) — an MI355X is required.
-    dtype: encoder operand mode. 'fp16x3' (default; split fp16 operands, three MFMA terms per product: tokens / atoms /
-    bonds equal the reference's at ~3/4 of the bf16 mode's throughput), 'bf16x3' (the same with the fp32 exponent range),
-    'fp32' (exact-fp32 MFMA, slowest), 'bf16' / 'fp16' (fastest; argmax decisions near a tie can differ)."""
+    dtype: encoder operand mode. 'fp16x3' (split fp16 operands, three MFMA terms per product: features equal the reference's
+    to fp32 rounding level), 'fp16x3m' (the same with the Linear layers of engine.FP16X3M_TWO_TERM on two terms: log-probs
+    within 5e-4 of the reference's), 'bf16x3' (three terms with the fp32 exponent range), 'fp32' (exact-fp32 MFMA, slowest),
+    'bf16' / 'fp16' (fastest; argmax decisions near a tie can differ). The default (engine.DEFAULT_DTYPE) is the fastest
+    mode whose tokens / atoms / bonds equal the reference's on both fixture checkpoints."""
 
-    def __init__(self, model_path, device=None, max_batch: int = 32, dtype: str = "fp16x3",
+    def __init__(self, model_path, device=None, max_batch: int = 32, dtype: str = DEFAULT_DTYPE,
                  device_preprocess: bool = True):
         if model_path is None:
             raise ValueError("molnextr(model_path): a checkpoint path is required (pass 'synthetic' explicitly for the "
@@ -180,6 +182,7 @@ class molnextr:
             warnings.warn(f"molnextr_amd: an encoder activation left the fp16 range of operand mode '{self.engine.dtype}' "
                           f"({e}); rebuilding the engine with dtype='{to}' and repeating the batch", RuntimeWarning)
             dev = self.engine.device
+            self._join_prefetch()       # the helper of group g + 1 may still be inside mnx_preprocess on this handle
             self.engine.close()
             self.engine = Engine(self._states["encoder"], self._states["decoder"], device=dev, max_batch=self._max_batch,
                                  dtype=to)
@@ -202,45 +205,70 @@ class molnextr:
             raise NotImplementedError("engine is built for the swin_base / 384 / discrete-coordinate configuration")
         return a
 
-    def _transform(self, images: List) -> torch.Tensor:
+    def _transform(self, images: List, engine=None) -> torch.Tensor:
         """CropWhite + Resize + ToGray + Normalize (reference model.py:104): on the device (mnx_preprocess), or with the
-        bit-identical host restatement when `device_preprocess` is off."""
+        bit-identical host restatement when `device_preprocess` is off. The result is a torch tensor of integer-exact
+        arithmetic: it does not depend on the engine's operand mode and outlives the engine that made it."""
         if self.device_preprocess:
-            return self.engine.preprocess(images)
+            return (engine or self.engine).preprocess(images)
         return torch.from_numpy(np.stack([transform_image(im, self.input_size) for im in images])).to(self.device)
+
+    _prefetch_thread = None       # the helper thread of the running _prefetched generator, if one is in flight
+
+    def _join_prefetch(self):
+        """Waits for the prefetch helper (if any). Called before the engine it works on is closed (_with_fallback)."""
+        t = self._prefetch_thread
+        if t is not None:
+            t.join()
+
+    def _side_context(self):
+        """The context the prefetch helper runs in: this device, a side stream (a seam for the CPU tests)."""
+        import contextlib
+        stack = contextlib.ExitStack()
+        stack.enter_context(torch.cuda.device(self.device))
+        stack.enter_context(torch.cuda.stream(torch.cuda.Stream(device=self.device)))
+        return stack
 
     def _prefetched(self, groups: List[List]):
         """Yields the transformed tensor of every group; group g+1 is uploaded (pinned staging -> H2D) and transformed on a
         side stream by a helper thread while the caller runs the engine on group g (reference main.py gets the same
         overlap from DataLoader workers + pin_memory). `mnx_preprocess` is the one entry point that may run beside
-        another call on the same handle (include/molnextr_hip.h)."""
+        another call on the same handle (include/molnextr_hip.h) — ONE such call: at most one helper exists at a time, it
+        works on the engine that was current when it was started, and whoever replaces that engine joins the helper first
+        (_with_fallback -> _join_prefetch); closing the generator (a call that is abandoned and restarted) joins it too."""
         if len(groups) <= 1 or not self.device_preprocess:
             for g in groups:
                 yield self._transform(g)
             return
         import threading
-        side = torch.cuda.Stream(device=self.device)
 
-        def work(g, box):
+        def work(g, box, engine):
             try:
-                with torch.cuda.device(self.device), torch.cuda.stream(side):
-                    box.append(self._transform(g))          # Engine.preprocess synchronises `side` before returning
+                with self._side_context():
+                    box.append(self._transform(g, engine))      # Engine.preprocess synchronises the side stream before returning
             except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
                 box.append(e)
 
-        box: list = []
-        t = threading.Thread(target=work, args=(groups[0], box), daemon=True)
-        t.start()
-        for gi in range(len(groups)):
+        def start(g):
+            box: list = []
+            t = threading.Thread(target=work, args=(g, box, self.engine), daemon=True)
+            self._prefetch_thread = t
+            t.start()
+            return t, box
+
+        t, box = start(groups[0])
+        try:
+            for gi in range(len(groups)):
+                t.join()
+                item = box.pop()
+                if isinstance(item, BaseException):
+                    raise item
+                if gi + 1 < len(groups):
+                    t, box = start(groups[gi + 1])
+                yield item
+        finally:
             t.join()
-            item = box.pop()
-            if isinstance(item, BaseException):
-                raise item
-            if gi + 1 < len(groups):
-                box = []
-                t = threading.Thread(target=work, args=(groups[gi + 1], box), daemon=True)
-                t.start()
-            yield item
+            self._prefetch_thread = None
 
     def predict_images(self, input_images: List, return_atoms_bonds=False, return_confidence=False, batch_size=16):
         if len(input_images) == 0:
@@ -269,10 +297,15 @@ class molnextr:
             # the group is a whole number of reference batches so that batch boundaries do not drift between groups
             group = (self.group_images // batch_size) * batch_size
             groups = [input_images[i:i + group] for i in range(0, len(input_images), group)]
-            for x in self._prefetched(groups):
-                preds += self._with_fallback(
-                    lambda eng: predict_pipeline(eng, x, self.tokenizer, ref_batch_size=batch_size))
-                self._groups_done += 1
+            gen = self._prefetched(groups)
+            try:
+                for x in gen:
+                    preds += self._with_fallback(
+                        lambda eng: predict_pipeline(eng, x, self.tokenizer, ref_batch_size=batch_size))
+                    self._groups_done += 1
+            finally:
+                if hasattr(gen, "close"):
+                    gen.close()         # a call abandoned by _RestartCall leaves no helper thread behind
         else:
             step = max(self.engine.max_batch // batch_size, 1) * batch_size
             for i in range(0, len(input_images), step):

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.mnx_abi_version() == engine.ABI_VERSION == 6
+    assert lib.mnx_abi_version() == engine.ABI_VERSION == 7
 
 
 def test_config_struct_layout_matches_header():

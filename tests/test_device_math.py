@@ -104,7 +104,8 @@ def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
     through inline asm that writes M0, a register the compiler does not track around asm. Both only hold if the generated
     code (1) has no scratch (spill) traffic — scratch loads / stores are vector-memory operations too —, (2) touches M0
     nowhere but in the `s_mov_b32 m0` in front of each of those DMA instructions, and (3) contains no wait the compiler
-    added on its own: exactly the five vmcnt(0) of the drain branches."""
+    added on its own: exactly the vmcnt(0) of the drain branches and the counts derived in the kernel, for the six-phase
+    (three terms) and the four-phase (two terms) loop alike."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -117,33 +118,51 @@ def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
                    check=True, capture_output=True)
     text = out.read_text()
     kernels = re.findall(r"^(_ZN3mnx12_GLOBAL__N_116gemm256x3_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert len(kernels) == 8                                   # {fp16, bf16} x {bias, bias + GELU, bias + residual fp32, bias fp32}
+    # bf16: three terms x {bias, bias + GELU, bias + residual fp32, bias fp32}; fp16: {three, two} terms x those four + the GELU
+    # epilogue that keeps the hi output plane only (its consumer runs on two terms)
+    assert len(kernels) == 4 + 2 * 5
+    seen = set()
     for name, body in kernels:
+        t, epi, terms, lo_out = re.search(r"kernelI(DF16_|DF16b)Li(\d)ELi(\d)ELb([01])E", name).groups()
+        epi, terms, lo_out = int(epi), int(terms), lo_out == "1"
+        seen.add((t, epi, terms, lo_out))
         assert "scratch_" not in body, name
         n_dma = len(re.findall(r"global_load_lds_dword", body))
         assert len(re.findall(r"\bm0\b", body)) == n_dma == len(re.findall(r"s_mov_b32 m0,", body)), name
         waits = sorted(int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
-        out16 = re.search(r"Li[01]E", name) is not None
+        out16 = epi in (0, 1)
+        # vector-memory operations of a tile's epilogue (+ 1 bias DMA) that are younger than the fills a first-K-tile wait covers
+        pst = (32 if lo_out else 16) if out16 else (64 if epi == 2 else 32)
+        if terms == 3:      # phase waits P1 P2 P4 P5 P6 (P3 waits for nothing): younger fills 10 10 12 12 2, prologue 8
+            normal, first, prologue = [10, 10, 12, 12, 2], [10 + pst + 1, 10 + pst + 1, 12 + pst + 1, 12 + 1, 2], 8
+        else:               # phase waits P1 P2 P4: younger fills 6 6 6, prologue 6
+            normal, first, prologue = [6, 6, 6], [6 + pst + 1, 6 + pst + 1, 6], 6
+        first = [min(w, 63) for w in first]
         if out16:
-            # one copy of the K-tile body: prologue 15 DMAs + 1 bias in P1 + 16 per K-tile; no compiler-made wait
-            assert n_dma == 32, (name, n_dma)
-            assert waits == [0, 0, 0, 0, 0, 2, 2, 8, 10, 10, 12, 12, 13, 43, 43, 45], (name, waits)
-            assert len(re.findall(r"s_barrier", body)) == 15, name
+            # one copy of the K-tile body: prologue DMAs (bias + every slot K-tile 0 needs) + 1 bias in P1 + the K-tile's fills; no
+            # compiler-made wait; 2 barriers per phase + 2 in the prologue + the closing one
+            assert n_dma == (32 if terms == 3 else 26), (name, n_dma)
+            assert waits == sorted([0] * len(normal) + normal + first + [prologue]), (name, waits)
+            assert len(re.findall(r"s_barrier", body)) == (15 if terms == 3 else 11), name
         else:
-            # fp32 epilogues (form 2, gemm256.hip MNX_X3_EPI32): residual loads and stores are inline asm on ONE scalar base
-            # per array + a 32-bit lane offset, retired by counted waits — four slabs of residual in flight, 12 16 20 24 24 20
-            # 16 12 younger operations allowed when slab 0..7 is consumed. The compiler sees no vector-memory operation in
-            # the epilogue, so it adds no wait of its own (it may duplicate the K-tile body and the two copies of the epilogue)
-            resid = "Li2E" in name
-            expect = {10: 2, 13: 1, 8: 1}
-            expect.update({63: 3} if resid else {43: 2, 45: 1})
+            # fp32 epilogues: residual loads and stores are inline asm on ONE scalar base per array + a 32-bit lane offset, retired
+            # by counted waits — four slabs of residual in flight, 12 16 20 24 24 20 16 12 younger operations allowed when slab
+            # 0..7 is consumed. The compiler sees no vector-memory operation in the epilogue, so it adds no wait of its own (it
+            # may duplicate the K-tile body and the two copies of the epilogue)
+            resid = epi == 2
+            expect = {}
+            for w in normal + first + [prologue]:
+                expect[w] = expect.get(w, 0) + 1
             for w, n in expect.items():
+                if w in (12, 16, 20, 24) and resid:
+                    continue                                          # shared with the epilogue's own counted waits, checked below
                 assert waits.count(w) >= n and waits.count(w) % n == 0, (name, w, waits.count(w))
             copies = waits.count(24) // 2 if resid else 0
             if resid:
                 assert copies >= 2 and waits.count(16) == 2 * copies and waits.count(20) == 2 * copies, (name, waits)
-                assert waits.count(12) >= 2 * copies + 2, (name, waits)          # + the two phase waits of 12
-            assert not any(w in waits for w in (1, 3, 4, 5, 6, 7)), (name, waits)     # what a compiler-made wait would look like
+                assert waits.count(12) >= 2 * copies + (2 if terms == 3 else 0), (name, waits)     # + the two phase waits of 12
+            allowed = set(normal + first + [prologue, 0]) | ({12, 16, 20, 24} if resid else set())
+            assert set(waits) <= allowed, (name, sorted(set(waits) - allowed))     # anything else would be a compiler-made wait
             ld = re.findall(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\]", body)
             st = re.findall(r"global_store_dwordx4 v\d+, v\[\d+:\d+\], s\[\d+:\d+\]", body)
             n_ld = len(re.findall(r"global_load_dwordx4", body)), len(re.findall(r"global_store_dwordx4", body))
@@ -174,6 +193,8 @@ def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
                             assert not (regs(nxt.split()[1].strip(",")) & data), (name, l, nxt)
                         ws += 1
                     k += 1
+    assert seen == ({("DF16b", e, 3, True) for e in range(4)} | {("DF16_", e, t, True) for e in range(4) for t in (2, 3)}
+                    | {("DF16_", 1, t, False) for t in (2, 3)})
 
 
 def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fetch_queue(tmp_path):

@@ -90,3 +90,58 @@ def test_a_fallback_after_the_first_group_restarts_the_whole_call(monkeypatch):
     assert [p["id"] for p in out] == [0, 1, 2, 3, 4] and {p["dtype"] for p in out} == {"bf16x3"}
     assert seen == [("fp16x3", [0, 1]), ("fp16x3", [2, 3]), ("bf16x3", [0, 1]), ("bf16x3", [2, 3]), ("bf16x3", [4])]
     assert m._groups_done == 0
+
+
+def test_the_prefetch_helper_never_touches_a_closed_engine_nor_shares_one_with_a_second_helper(monkeypatch):
+    """the facade uploads + transforms group g + 1 on a helper thread while the engine works on group g.
+    When group g trips the range flag, the engine is closed and replaced — the helper may still be inside mnx_preprocess on
+    the old handle (use-after-free), or, after the swap, a second helper of the restarted call could run preprocess on the
+    new handle beside it. Here with the REAL _prefetched generator (stub engines whose preprocess takes a while and records
+    what it sees): no preprocess call may observe its engine closed, no two may overlap on one engine, the abandoned
+    generator's helper is joined, and the restarted call still returns every image once, in the fallback mode."""
+    import contextlib
+    import threading
+    import time
+
+    events, lock = [], threading.Lock()
+
+    class _SlowEngine(_StubEngine):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            self.busy = 0
+
+        def preprocess(self, images):
+            with lock:
+                self.busy += 1
+                events.append(("enter", id(self), self.closed, self.busy))
+            time.sleep(0.05)
+            with lock:
+                events.append(("exit", id(self), self.closed, self.busy))
+                self.busy -= 1
+            return list(images)
+
+    monkeypatch.setattr(M, "Engine", _SlowEngine)
+    _StubEngine.built = []
+    m = M.molnextr.__new__(M.molnextr)
+    m._states, m._max_batch = {"encoder": {}, "decoder": {}}, 8
+    m.engine = _SlowEngine({}, {}, device=0, max_batch=8, dtype="fp16x3")
+    m.group_images, m.tokenizer, m.device_preprocess = 2, None, True
+    monkeypatch.setattr(M.molnextr, "_side_context", lambda self: contextlib.nullcontext())
+    monkeypatch.setattr(M.molnextr, "_assemble", lambda self, preds, imgs, a, c: preds)
+
+    def fake_pipeline(eng, x, tok, ref_batch_size=16):
+        assert not eng.closed
+        if eng.dtype == "fp16x3" and 2 in x:
+            raise MnxError("mnx_predict failed (-6)", code=MNX_ERR_RANGE)     # while the helper is inside preprocess of group 3
+        time.sleep(0.01)
+        return [{"id": i, "dtype": eng.dtype} for i in x]
+
+    monkeypatch.setattr(M, "predict_pipeline", fake_pipeline)
+    n_threads = threading.active_count()
+    with pytest.warns(RuntimeWarning, match="bf16x3"):
+        out = m.predict_images(list(range(9)), batch_size=2)
+    assert [p["id"] for p in out] == list(range(9)) and {p["dtype"] for p in out} == {"bf16x3"}
+    assert all(not closed for (_, _, closed, _) in events), "a preprocess call ran on (or across the close of) a closed engine"
+    assert all(busy == 1 for (_, _, _, busy) in events), "two preprocess calls overlapped on one engine handle"
+    assert m._prefetch_thread is None and threading.active_count() == n_threads, "a helper thread was left behind"
+    assert len(_StubEngine.built) == 2 and _StubEngine.built[0].closed and not _StubEngine.built[1].closed

@@ -127,6 +127,68 @@ def test_gemm_split_operand_modes(dev, dtype, M, N, K):
     e.close()
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 96, 32), (129, 136, 72), (1000, 384, 128), (2304, 128, 512), (4608, 1024, 4096),
+                                   (16384, 1024, 256), (18432, 2048, 512), (65536, 256, 128), (65536, 512, 128)])
+def test_gemm_two_term_form(dev, M, N, K):
+    """SplitArgs::terms == 2 (compute_dtype FP16X3M: C = oscale (Ah.Wh + Ah.Wl) + bias, the activation's lo plane neither read
+    nor multiplied) on both kernels — the 128-tile one (DMA and non-DMA K loops) and the four-phase form of the persistent
+    256x256 kernel (the last five shapes; one, two and several K-tiles per tile, several tiles per workgroup, a ragged round)
+    — against a float64 product of the ROUNDED activation (the hi plane) with the unrounded weight, every output element,
+    all four epilogues; the one-plane output (hi only, for a two-term consumer) is the two-plane output's hi plane bit for bit;
+    and the two kernels add the same fp32 numbers in the same order (an image's features must not depend on which kernel
+    its rows land in: launch_gemm16 splits a layer's rows between them by batch size)."""
+    e = _tiny_engine("fp16x3")
+    td = torch.float16
+    g = torch.Generator().manual_seed(M + N + K + 2)
+    A = torch.randn(M, K, generator=g).to(dev)
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    wscale = 2.0 ** 12
+    A2, W2 = _split_planes(A, td), _split_planes(Wt, td, wscale)
+    A2[1].fill_(float("nan"))                                            # the lo plane of A must not be touched
+    ref = A2[0].double() @ Wt.double().t() + bias.double()
+    tol = 3e-6
+    out = torch.zeros(M, N, device=dev)
+    e.gemm16_split(3, A2, W2, out, bias, oscale=1.0 / wscale, terms=2)
+    assert (out.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    o128 = torch.zeros(M, N, device=dev)
+    e.gemm16_split(3 | 0x200, A2, W2, o128, bias, oscale=1.0 / wscale, terms=2)
+    assert torch.equal(o128, out), "four-phase 256x256 kernel and 128x128 kernel must agree bit for bit"
+    full = A.double() @ Wt.double().t() + bias.double()
+    assert (out.double() - full).abs().max().item() > 20 * tol, "the activation's rounding must be visible (else lo was read)"
+    res = torch.randn(M, N, generator=g).to(dev)
+    r2 = res.clone()
+    e.gemm16_split(2, A2, W2, r2, bias, oscale=1.0 / wscale, terms=2)
+    assert (r2.double() - (ref + res.double())).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    r128 = res.clone()
+    e.gemm16_split(2 | 0x200, A2, W2, r128, bias, oscale=1.0 / wscale, terms=2)
+    assert torch.equal(r128, r2)
+    for epi, want in ((0, ref), (1, torch.nn.functional.gelu(ref))):
+        o2 = torch.zeros(2, M, N, device=dev, dtype=td)
+        e.gemm16_split(epi, A2, W2, o2, bias, oscale=1.0 / wscale, terms=2)
+        got = o2[0].double() + o2[1].double()
+        assert (got - want).abs().max().item() < tol * max(1.0, want.abs().max().item()), epi
+        o128 = torch.zeros(2, M, N, device=dev, dtype=td)
+        e.gemm16_split(epi | 0x200, A2, W2, o128, bias, oscale=1.0 / wscale, terms=2)
+        assert torch.equal(o128, o2), epi
+        if epi == 1:        # the GELU epilogue with one output plane (fc1 when fc2 runs on two terms), both term counts
+            for terms in (2, 3):
+                a_in = A2 if terms == 2 else _split_planes(A, td)
+                two = torch.zeros(2, M, N, device=dev, dtype=td)
+                e.gemm16_split(1, a_in, W2, two, bias, oscale=1.0 / wscale, terms=terms)
+                one = torch.full((1, M, N), 3.0, device=dev, dtype=td)
+                e.gemm16_split(1 | 0x400, a_in, W2, one, bias, oscale=1.0 / wscale, terms=terms)
+                assert torch.equal(one[0], two[0]), terms
+                one128 = torch.full((1, M, N), 3.0, device=dev, dtype=td)
+                e.gemm16_split(1 | 0x400 | 0x200, a_in, W2, one128, bias, oscale=1.0 / wscale, terms=terms)
+                assert torch.equal(one128[0], two[0]), terms
+    e.close()
+    eb = _tiny_engine("bf16x3")
+    with pytest.raises(Exception):          # bf16 operands never run on two terms
+        eb.gemm16_split(3, A2.to(torch.bfloat16), W2.to(torch.bfloat16), out, bias, terms=2)
+    eb.close()
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", [(65536, 256, 128), (16384, 1024, 256), (18432, 2048, 512), (9216, 3072, 1024)])
 def test_gemm_persistent_256_tile_kernel(dev, dtype, M, N, K):

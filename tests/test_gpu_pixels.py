@@ -8,6 +8,10 @@ Nothing of the GPU's output is handed to the checker. Per encoder operand mode:
     and `fp32` (exact-fp32 MFMA): logits of steps 0..3 and the log-prob of every emitted token within 1e-3 (north_star's
     tolerance), every token id, length, atom position, coordinate and bond class EXACT for all 32 + 6 images,
     molecule-like and plain-random decoder, free-running AND teacher-forced;
+  * `fp16x3m` (fp16x3 with fc1 + fc2 on TWO terms — the activation's lo plane dropped; 64 % of the encoder's GEMM time): the
+    exact-mode assertions unchanged (0 flips over every teacher-forced step, every free-running row and every molecule exact,
+    both checkpoints) with logits / log-probs within 5e-4 — north_star's 1e-3 with 2x headroom, the gate the round-5 review
+    set for making it a shippable mode;
   * `bf16x3` (split bf16 operands): the same logit gate (1e-3); token flips are allowed only where the teacher-forced
     trace proves a near-tie (below);
   * `fp16` / `bf16` (one 16-bit plane per operand, the fastest modes): measured, with gates at 2x the values committed in
@@ -34,11 +38,13 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("m6", 6, 480, True), ("m32", 32, 480, True), ("p6", 6, 64, False), ("p32", 32, 64, False)]
-EXACT_MODES = ("fp32", "fp16x3")
+EXACT_MODES = ("fp32", "fp16x3", "fp16x3m")
 # max |logit error| over steps 0..3 and max |log-prob error| along the reference trajectory; max |feature error| (features
 # have unit rms). Exact modes and bf16x3: north_star's 1e-3. 16-bit modes: 2x the measured values (profiles/r03_pixels_parity.json).
-LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "bf16x3": 1e-3, "fp16": 2e-2, "bf16": 1.2e-1}
-FEAT_TOL = {"fp32": 5e-5, "fp16x3": 5e-5, "bf16x3": 3e-4, "fp16": 7e-3, "bf16": 4.5e-2}
+# fp16x3m: 5e-4 on logits / log-probs (the review's gate; CPU emulation tools/study_split_terms.py --two fc1,fc2: 4.3e-4 / 4.2e-4
+# on the two checkpoints), features 2x the emulation's 1.3e-3 max.
+LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 5e-4, "bf16x3": 1e-3, "fp16": 2e-2, "bf16": 1.2e-1}
+FEAT_TOL = {"fp32": 5e-5, "fp16x3": 5e-5, "fp16x3m": 2.6e-3, "bf16x3": 3e-4, "fp16": 7e-3, "bf16": 4.5e-2}
 FLIP_MARGIN_FACTOR = 2.0
 
 
@@ -102,7 +108,7 @@ def _teacher_forced(eng, feats, g_ids, g_lens, g_lp, g_margin, max_len):
     return err, flips, steps
 
 
-@pytest.mark.parametrize("mode", ["fp16x3", "fp32", "bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("mode", ["fp16x3", "fp16x3m", "fp32", "bf16x3", "fp16", "bf16"])
 def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
     from molnextr_amd.model import predict_pipeline
     dev = torch.device("cuda:0")
@@ -171,7 +177,7 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
             tot_steps += tf_steps
             if exact:
                 assert not first_div, (mode, name, rec["first_divergence"])
-                assert lp_err < 1e-3, (mode, name, lp_err)
+                assert lp_err < LOGIT_TOL[mode], (mode, name, lp_err)
             elif first_div:
                 # the earliest divergence of the batch (later ones can be knock-on effects of the batch-row positional
                 # encoding) happens with the reference history intact, so it must be one of the teacher-forced flips
@@ -214,10 +220,12 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
 # feature tolerances on the stress checkpoint: 4x what tools/study_split_terms.py --ckpt stress predicts on the CPU
 # (profiles/r04_stress_emulation.json: fp16x3 max err 2.6e-5 / rms 1.2e-6, bf16x3 2.7e-4 / 1.4e-5 on unit-rms features; the
 # largest operands it sees: 499 into fc1, 183 into fc2, 79 in the residual stream — far from the fp16 limit)
-STRESS_FEAT_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "bf16x3": 1.2e-3}
+# fp16x3m: 2x the emulation's --two fc1,fc2 row (profiles/r06_two_term_study_stress.json: max 9.0e-3 — the outlier channels —, rms 4.2e-4)
+STRESS_FEAT_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16x3m": 1.8e-2, "bf16x3": 1.2e-3}
+STRESS_LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 5e-4, "bf16x3": 1e-3}
 
 
-@pytest.mark.parametrize("mode", ["fp16x3", "bf16x3", "fp32"])
+@pytest.mark.parametrize("mode", ["fp16x3", "fp16x3m", "bf16x3", "fp32"])
 def test_stress_checkpoint_from_pixels_vs_reference(mode, golden_dir):
     """The exact-mode assertions of test_path_from_pixels_vs_reference on a SECOND, hostile checkpoint
     (W.synthetic_checkpoint(1, stress=True): LayerNorm gains 0.1..8 with x50 outliers, per-matrix weight scales over a 40x
@@ -242,13 +250,13 @@ def test_stress_checkpoint_from_pixels_vs_reference(mode, golden_dir):
         assert ferr < STRESS_FEAT_TOL[mode], (mode, ferr)
         ids, lens, lp, margin = (g[f"s16_{k}"] for k in ("ids", "lens", "token_logp", "margin"))
         tf_err, flips, steps = _teacher_forced(eng, feats, ids, lens, lp, margin, 480)
-        assert tf_err < 1e-3, (mode, tf_err)
+        assert tf_err < STRESS_LOGIT_TOL[mode], (mode, tf_err)
         for (b, t, m) in flips:
             assert m < FLIP_MARGIN_FACTOR * tf_err, (mode, "flip away from a near-tie", b, t, m, tf_err)
         out = eng.decode_greedy(feats, max_len=480, trace_logits=True)
         lg = out["logits"].cpu().numpy()
         logit_err = max(float(np.abs(lg[s] - g[f"s16_logits_step{s}"]).max()) for s in range(4))
-        assert logit_err < 1e-3, (mode, logit_err)
+        assert logit_err < STRESS_LOGIT_TOL[mode], (mode, logit_err)
         rec = {"feature_max_err": ferr, "feature_rms_err": frms, "feature_rms": float(g["feat_rms"][0]),
                "logit_max_err_steps0_3": logit_err,
                "teacher_forced": {"steps": steps, "logp_max_err": tf_err, "flips": len(flips)},
@@ -272,10 +280,11 @@ def test_stress_checkpoint_from_pixels_vs_reference(mode, golden_dir):
             # near-tie by the teacher-forced yardstick (margin < FLIP_MARGIN_FACTOR x the measured log-prob error); on this
             # fixture (minimum margin 2.7e-3, log-prob error 4e-5) that never happens: 16 / 16 rows and molecules.
             toks, ln = out["tokens"].cpu().numpy(), out["lengths"].cpu().numpy()
-            rows_exact = 0
+            rows_exact, exact_rows = 0, set()
             for b in range(16):
                 if ln[b] == lens[b] and np.array_equal(toks[b, :lens[b]], ids[b, :lens[b]]):
                     rows_exact += 1
+                    exact_rows.add(b)
                     continue
                 n = int(min(ln[b], lens[b]))
                 diff = np.nonzero(toks[b, :n] != ids[b, :n])[0]
@@ -286,11 +295,13 @@ def test_stress_checkpoint_from_pixels_vs_reference(mode, golden_dir):
             mol_exact = 0
             for b, (p, q) in enumerate(zip(preds, gpreds)):
                 c = p["chartok_coords"]
-                mol_exact += int(c["smiles"] == q["smiles"] and c["symbols"] == q["symbols"] and c["indices"] == q["indices"]
-                                 and c["coords"] == q["coords"] and p["edges"] == q["edges"])
+                atoms_same = (c["smiles"] == q["smiles"] and c["symbols"] == q["symbols"] and c["indices"] == q["indices"]
+                              and c["coords"] == q["coords"])
+                mol_exact += int(atoms_same and p["edges"] == q["edges"])
+                if b in exact_rows:         # a row whose tokens are the reference's gives the reference's atoms
+                    assert atoms_same, (mode, "molecule", b, "tokens agree with the reference but the atom set does not")
             rec["free_running_rows_exact"] = rows_exact
             rec["molecules_exact_atoms_bonds"] = mol_exact
-            assert mol_exact >= rows_exact - 0 or rows_exact < 16      # a molecule can only differ where its row does
             if not flips:
                 assert rows_exact == 16 and mol_exact == 16, (mode, rows_exact, mol_exact)
         _report("stress_" + mode, rec)

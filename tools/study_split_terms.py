@@ -13,7 +13,7 @@ decoder TEACHER-FORCED along the reference ids of tests/golden/pixels_e2e.npz: f
 error, argmax flips over all steps. The fp16x3 / bf16x3 / fp16 / bf16 rows reproduce what the GPU measures (DESIGN.md
 section 6.1), which is what makes the fp8 rows believable.
 
-  python tests/study_split_terms.py [--images 32] [--schemes fp16x3,bf16x3,...] [--ckpt 0|stress] [--ranges]
+  python tools/study_split_terms.py [--images 32] [--schemes fp16x3,bf16x3,...] [--ckpt 0|stress] [--ranges]
 """
 import argparse
 import json
@@ -63,9 +63,17 @@ class Scheme:
     """mm(a, w): a [..., K] activations, w [N, K] (or [..., N, K]) 'weight-like' operand -> a @ w^T in fp32 after the scheme's
     operand rounding. w_is_weight: per-matrix power-of-two pre-scale (fp16 split only)."""
 
-    def __init__(self, name):
+    def __init__(self, name, two=()):
         self.name = name
         self.amax = {}
+        # op classes (tags "qkv", "proj", "fc1", "fc2", "merge", "qk", "pv"; optionally "tag.sN" = only in stage N, 0-based) that
+        # drop the activation's lo plane: a.w = ah.wh + ah.wl (two MFMA terms; the weight keeps both planes). Everything else
+        # follows the scheme's name. The GPU form of this is compute_dtype FP16X3M (mnx_set_op_terms).
+        self.two = set(two)
+        self.stage = 0
+
+    def is_two(self, tag):
+        return tag in self.two or f"{tag}.s{self.stage}" in self.two
 
     def note(self, tag, *ts):
         m = max(float(t.abs().max()) for t in ts)
@@ -90,7 +98,9 @@ class Scheme:
         ah, al = split(a, dt)
         wh, wl = split(ws, dt)
         main = ah @ wh.transpose(-1, -2)
-        if n in ("fp16x3", "bf16x3"):
+        if n in ("fp16x3", "bf16x3") and self.is_two(tag):
+            corr = ah @ wl.transpose(-1, -2)
+        elif n in ("fp16x3", "bf16x3"):
             corr = ah @ wl.transpose(-1, -2) + al @ wh.transpose(-1, -2)
         elif n == "fp16+fp8x2":          # both correction terms on block-scaled e4m3 operands
             corr = mx8(ah) @ mx8(wl).transpose(-1, -2) + mx8(al) @ mx8(wh).transpose(-1, -2)
@@ -149,6 +159,7 @@ def swin_block(x, H, Wd, sd, p, heads, ws, shift, S):
 def encoder(img, sd, S, cfg=SWIN_B_384):
     x, H, Wd = OS.patch_embed(img.float(), sd, cfg)           # fp32 in every mode (patch_embed_kernel)
     for s, (depth, heads) in enumerate(zip(cfg.depths, cfg.heads)):
+        S.stage = s
         for b in range(depth):
             shift = 0 if b % 2 == 0 else cfg.window // 2
             x = swin_block(x, H, Wd, sd, f"transformer.layers.{s}.blocks.{b}", heads, cfg.window, shift, S)
@@ -260,6 +271,10 @@ def main():
     ap.add_argument("--kv", default=None,
                     help="K / V cache byte study instead of the operand schemes: comma list of bf16,fp16,bf16+8,fp16+8 — the decoder "
                          "runs teacher-forced on the fp32 features with every cached key / value rounded to that format")
+    ap.add_argument("--two", action="append", default=[],
+                    help="repeatable: comma list of op classes that run on TWO terms (ah.wh + ah.wl: the activation's lo plane is "
+                         "dropped) inside the split schemes, e.g. --two fc1,fc2 --two fc1,fc2,qkv.s2 ; one table row per option "
+                         "and split scheme of --schemes (tags qkv proj fc1 fc2 merge qk pv, '.sN' restricts to stage N)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     torch.set_num_threads(int(os.environ.get("STUDY_THREADS", "8")))
@@ -306,14 +321,17 @@ def main():
             with open(args.out, "w") as fo:
                 json.dump({"checkpoint": args.ckpt, "case": case, "study": "K/V cache bytes", "rows": rows}, fo, indent=1)
         return
-    for name in args.schemes.split(","):
+    runs = [(name, ()) for name in args.schemes.split(",") if name]
+    runs += [(name, tuple(t for t in two.split(",") if t)) for two in args.two for name in args.schemes.split(",")
+             if name in ("fp16x3", "bf16x3")]
+    for name, two in runs:
         t0 = time.time()
-        S = Scheme(name)
+        S = Scheme(name, two)
         f = torch.cat([encoder(img[i:i + 4], ck["encoder"], S) for i in range(0, N, 4)])
         d = (f - ref)
         lp, fl = forced_decode(f, ck["decoder"], ids, lens)
         fm = [float(margin[b, t]) for b, t in zip(*np.nonzero(fl & m))]
-        rec = {"scheme": name, "images": N, "feature_max_err": float(d.abs().max()), "feature_rms_err": float(d.pow(2).mean().sqrt()),
+        rec = {"scheme": name, "two_terms": ",".join(two), "images": N, "feature_max_err": float(d.abs().max()), "feature_rms_err": float(d.pow(2).mean().sqrt()),
                "logp_max_err": float(np.abs(lp - lp_ref)[m].max()), "flips": int((fl & m).sum()), "steps": steps,
                "flip_margins": [round(x, 6) for x in fm[:20]], "seconds": round(time.time() - t0)}
         if args.ranges:
