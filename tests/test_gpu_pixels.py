@@ -8,10 +8,10 @@ Nothing of the GPU's output is handed to the checker. Per encoder operand mode:
     and `fp32` (exact-fp32 MFMA): logits of steps 0..3 and the log-prob of every emitted token within 1e-3 (north_star's
     tolerance), every token id, length, atom position, coordinate and bond class EXACT for all 32 + 6 images,
     molecule-like and plain-random decoder, free-running AND teacher-forced;
-  * `fp16x3m` (fp16x3 with fc1 + fc2 on TWO terms — the activation's lo plane dropped; 64 % of the encoder's GEMM time): the
-    exact-mode assertions unchanged (0 flips over every teacher-forced step, every free-running row and every molecule exact,
-    both checkpoints) with logits / log-probs within 5e-4 — north_star's 1e-3 with 2x headroom, the gate the round-5 review
-    set for making it a shippable mode;
+  * `fp16x3m` (fp16x3 with the Linears of engine.FP16X3M_TWO_TERM on TWO terms — the activation's lo plane dropped; opt-in):
+    the exact-mode assertions unchanged (0 flips over every teacher-forced step, every free-running row and every molecule
+    exact, both checkpoints), log-probs within 5e-4 (measured 1.8e-4) and raw logits within 6e-4 (measured 4.96e-4: the
+    round-5 review's 5e-4 gate for a DEFAULT mode is met without margin, which is why the mode stays opt-in);
   * `bf16x3` (split bf16 operands): the same logit gate (1e-3); token flips are allowed only where the teacher-forced
     trace proves a near-tie (below);
   * `fp16` / `bf16` (one 16-bit plane per operand, the fastest modes): measured, with gates at 2x the values committed in
@@ -41,9 +41,10 @@ CASES = [("m6", 6, 480, True), ("m32", 32, 480, True), ("p6", 6, 64, False), ("p
 EXACT_MODES = ("fp32", "fp16x3", "fp16x3m")
 # max |logit error| over steps 0..3 and max |log-prob error| along the reference trajectory; max |feature error| (features
 # have unit rms). Exact modes and bf16x3: north_star's 1e-3. 16-bit modes: 2x the measured values (profiles/r03_pixels_parity.json).
-# fp16x3m: 5e-4 on logits / log-probs (the review's gate; CPU emulation tools/study_split_terms.py --two fc1,fc2: 4.3e-4 / 4.2e-4
-# on the two checkpoints), features 2x the emulation's 1.3e-3 max.
-LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 5e-4, "bf16x3": 1e-3, "fp16": 2e-2, "bf16": 1.2e-1}
+# fp16x3m: raw logits 6e-4 (measured 4.96e-4, profiles/r06_two_term_tables_gpu.json), log-probs 5e-4 (LOGP_TOL; measured 1.8e-4),
+# features 2x the CPU emulation's 1.3e-3 max (profiles/r06_two_term_study*.json).
+LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 6e-4, "bf16x3": 1e-3, "fp16": 2e-2, "bf16": 1.2e-1}
+LOGP_TOL = dict(LOGIT_TOL, fp16x3m=5e-4)
 FEAT_TOL = {"fp32": 5e-5, "fp16x3": 5e-5, "fp16x3m": 2.6e-3, "bf16x3": 3e-4, "fp16": 7e-3, "bf16": 4.5e-2}
 FLIP_MARGIN_FACTOR = 2.0
 
@@ -132,7 +133,7 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
             fb = feats[:B].contiguous()
             # (1) teacher-forced along the reference trajectory: log-prob error at EVERY step, independent flips
             tf_err, flips, tf_steps = _teacher_forced(eng, fb, g_ids, g_lens, g_lp, g_margin, max_len)
-            assert tf_err < LOGIT_TOL[mode], (mode, name, tf_err)
+            assert tf_err < LOGP_TOL[mode], (mode, name, tf_err)
             for (b, t, m) in flips:
                 assert m < FLIP_MARGIN_FACTOR * tf_err, (mode, name, "flip away from a near-tie", b, t, m, tf_err)
             if exact:
@@ -177,7 +178,7 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
             tot_steps += tf_steps
             if exact:
                 assert not first_div, (mode, name, rec["first_divergence"])
-                assert lp_err < LOGIT_TOL[mode], (mode, name, lp_err)
+                assert lp_err < min(1e-3, LOGP_TOL[mode]), (mode, name, lp_err)
             elif first_div:
                 # the earliest divergence of the batch (later ones can be knock-on effects of the batch-row positional
                 # encoding) happens with the reference history intact, so it must be one of the teacher-forced flips
@@ -222,7 +223,8 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
 # largest operands it sees: 499 into fc1, 183 into fc2, 79 in the residual stream — far from the fp16 limit)
 # fp16x3m: 2x the emulation's --two fc1,fc2 row (profiles/r06_two_term_study_stress.json: max 9.0e-3 — the outlier channels —, rms 4.2e-4)
 STRESS_FEAT_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16x3m": 1.8e-2, "bf16x3": 1.2e-3}
-STRESS_LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 5e-4, "bf16x3": 1e-3}
+STRESS_LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 6e-4, "bf16x3": 1e-3}
+STRESS_LOGP_TOL = dict(STRESS_LOGIT_TOL, fp16x3m=5e-4)
 
 
 @pytest.mark.parametrize("mode", ["fp16x3", "fp16x3m", "bf16x3", "fp32"])
@@ -250,7 +252,7 @@ def test_stress_checkpoint_from_pixels_vs_reference(mode, golden_dir):
         assert ferr < STRESS_FEAT_TOL[mode], (mode, ferr)
         ids, lens, lp, margin = (g[f"s16_{k}"] for k in ("ids", "lens", "token_logp", "margin"))
         tf_err, flips, steps = _teacher_forced(eng, feats, ids, lens, lp, margin, 480)
-        assert tf_err < STRESS_LOGIT_TOL[mode], (mode, tf_err)
+        assert tf_err < STRESS_LOGP_TOL[mode], (mode, tf_err)
         for (b, t, m) in flips:
             assert m < FLIP_MARGIN_FACTOR * tf_err, (mode, "flip away from a near-tie", b, t, m, tf_err)
         out = eng.decode_greedy(feats, max_len=480, trace_logits=True)
@@ -379,3 +381,88 @@ def test_one_term_attention_measured_in_flips_on_both_checkpoints(gold, images, 
         finally:
             eng.close()
     _report("attention_one_term", rec)
+
+
+# Two-term tables measured on the GPU (tags as Engine.set_op_terms / tools/study_split_terms.py --two). The first entry is the
+# table compute_dtype FP16X3M ships (engine.FP16X3M_TWO_TERM = include/molnextr_hip.h MNX_FP16X3M_TWO_TERM_BY_STAGE).
+TWO_TERM_TABLES = {
+    "fp16x3m (shipped)": None,
+    "fc1,fc2 every stage (round-5 review's proposal)": ("fc1", "fc2"),
+    "stage 3: fc1 fc2": ("fc1.s2", "fc2.s2"),
+    "stage 3: qkv fc1 fc2": ("qkv.s2", "fc1.s2", "fc2.s2"),
+    "stage 3: proj fc1 fc2": ("proj.s2", "fc1.s2", "fc2.s2"),
+    "stage 3: qkv proj fc1 fc2": ("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2"),
+    "stages 3+4: fc1 fc2": ("fc1.s2", "fc2.s2", "fc1.s3", "fc2.s3"),
+    "stage 3: qkv fc1 fc2 + stage 4: fc1 fc2": ("qkv.s2", "fc1.s2", "fc2.s2", "fc1.s3", "fc2.s3"),
+    "stages 3+4: qkv fc1 fc2": ("qkv.s2", "fc1.s2", "fc2.s2", "qkv.s3", "fc1.s3", "fc2.s3"),
+    "stages 3+4: qkv proj fc1 fc2": ("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2", "qkv.s3", "proj.s3", "fc1.s3", "fc2.s3"),
+    "every Linear of every stage": ("qkv", "proj", "fc1", "fc2", "merge"),
+}
+
+
+def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, golden_dir):
+    """Which Linear layers can drop the activation's lo plane (two MFMA terms instead of three)? fp16x3 engines, the table
+    switched with mnx_set_op_terms (same weights, same kernels): features vs the reference, raw logits of steps 0..3 and
+    teacher-forced log-prob error + argmax flips along the reference ids — on the four cases of the molecule-like fixture (6 and
+    32 rows, trained-like and plain decoder: 6855 steps) and on the hostile checkpoint (16 rows, 6008 steps). Recorded for every
+    table (profiles/r06_two_term_tables_gpu.json is this test's report); asserted for the SHIPPED table: 0 flips, log-probs within
+    5e-4 and raw logits within 6e-4 everywhere (measured 1.8e-4 / 4.96e-4; north_star: 1e-3) — and for every table 0 flips (the
+    record shows what each costs: no table of useful size leaves the raw logits under 5e-4 with margin, so the mode is opt-in).
+    The CPU emulation of the same tables: profiles/r06_two_term_study*.json."""
+    from molnextr_amd.engine import Engine, FP16X3M_TWO_TERM
+    dev = torch.device("cuda:0")
+    gs = dict(np.load(os.path.join(golden_dir, "pixels_stress.npz")))
+    stress_ck = W.synthetic_checkpoint(1, stress=True)
+    mol, pln = _engines("fp16x3", synth_ckpt)
+    st = Engine(stress_ck["encoder"], stress_ck["decoder"], device=0, max_batch=16, dtype="fp16x3", dec_slots=64)
+    rec = {}
+    try:
+        x = images.to(dev)
+        xs = W.synthetic_images(16, first_index=700).to(dev)
+
+        def measure(eng, feats, g, case, n, max_len):
+            ids, lens, lp, margin = (g[f"{case}_{k}"] for k in ("ids", "lens", "token_logp", "margin"))
+            fb = feats[:n].contiguous()
+            err, flips, steps = _teacher_forced(eng, fb, ids, lens, lp, margin, max_len)
+            lg = eng.decode_greedy(fb, max_len=max_len, trace_logits=True)["logits"].cpu().numpy()
+            logit_err = max(float(np.abs(lg[s] - g[f"{case}_logits_step{s}"]).max()) for s in range(4))
+            return {"logit_max_err_steps0_3": logit_err, "logp_max_err": err, "flips": len(flips), "steps": steps}
+
+        for name, table in TWO_TERM_TABLES.items():
+            tags = FP16X3M_TWO_TERM if table is None else table
+            for e in (mol, pln, st):
+                e.set_op_terms(tags)
+            feats = mol.encode(x)
+            f = feats.cpu().numpy()[:, ::9, ::16]
+            r = {"two_term": list(tags), "e2e": {"feature_max_err": float(np.abs(f - gold["feat_strided"]).max()),
+                                                 "feature_rms_err": float(np.sqrt(((f - gold["feat_strided"]) ** 2).mean()))}}
+            for case, n, max_len, is_mol in CASES:
+                r["e2e"][case] = measure(mol if is_mol else pln, feats, gold, case, n, max_len)
+            fs = st.encode(xs)
+            f = fs.cpu().numpy()[:, ::9, ::16]
+            r["stress"] = {"feature_max_err": float(np.abs(f - gs["feat_strided"]).max()),
+                           "feature_rms_err": float(np.sqrt(((f - gs["feat_strided"]) ** 2).mean())),
+                           "s16": measure(st, fs, gs, "s16", 16, 480)}
+            r["logit_max_err"] = max([r["e2e"][c]["logit_max_err_steps0_3"] for c, *_ in CASES] + [r["stress"]["s16"]["logit_max_err_steps0_3"]])
+            r["logp_max_err"] = max([r["e2e"][c]["logp_max_err"] for c, *_ in CASES] + [r["stress"]["s16"]["logp_max_err"]])
+            r["flips"] = sum(r["e2e"][c]["flips"] for c, *_ in CASES) + r["stress"]["s16"]["flips"]
+            rec[name] = r
+        mol.set_op_terms(())
+        again = mol.encode(x)
+        eng2 = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dtype="fp16x3m", dec_slots=64)
+        try:
+            mol.set_op_terms(FP16X3M_TWO_TERM)
+            assert torch.equal(eng2.encode(x), mol.encode(x)), "FP16X3M == FP16X3 + its table (same weights, same kernels)"
+        finally:
+            eng2.close()
+        mol.set_op_terms(())
+        assert torch.equal(again, mol.encode(x)), "clearing the table restores the three-term result bit for bit"
+    finally:
+        mol.close()
+        pln.close()
+        st.close()
+    _report("two_term_tables", rec)
+    for name, r in rec.items():
+        assert r["flips"] == 0, (name, r)
+        if name.startswith("fp16x3m"):
+            assert r["logp_max_err"] < 5e-4 and r["logit_max_err"] < 6e-4, (name, r["logp_max_err"], r["logit_max_err"])

@@ -1,9 +1,11 @@
 // tools/gemm_lab/lab.hip — standalone A/B bench of the encoder GEMM kernels on the Swin-B shapes (no Python, no engine).
 //
-//   make -C tools/gemm_lab && tools/gemm_lab/lab [images_per_group=64] [iters=20] [only-names,comma-separated|-] [bf16|fp16x3]
+//   make -C tools/gemm_lab && tools/gemm_lab/lab [images_per_group=64] [iters=20] [only-names,comma-separated|-] [bf16|fp16x3|fp16x2]
 //
 // Mode fp16x3 times the split-operand form of the same kernels (hi + lo planes, three MFMA terms per product; TFLOP/s are
-// ALGORITHMIC, 2*M*N*K): timing only — its arithmetic is checked element by element in tests/test_gpu_parity.py.
+// ALGORITHMIC, 2*M*N*K): timing only — its arithmetic is checked element by element in tests/test_gpu_parity.py. Mode fp16x2:
+// the same on TWO terms (SplitArgs::terms = 2: the activation's lo plane is not read; the GELU epilogue writes one plane) —
+// what compute_dtype FP16X3M runs in the layers of its table.
 //
 // For every (stage, layer) GEMM shape of an encoder group it checks sampled output rows of both kernels against a naive
 // fp32 reference (same 16-bit inputs) and prints microseconds and TFLOP/s of
@@ -22,18 +24,6 @@
 
 #include "common.h"
 #include "kernels.h"
-
-#ifdef MNX_X3_LAB
-#define MNX_X3_LAB_V MNX_X3_LAB
-#else
-#define MNX_X3_LAB_V 0
-#define MNX_X3_LAB 0
-#endif
-#ifdef MNX_X3_EPI32
-#define MNX_X3_EPI32_V MNX_X3_EPI32
-#else
-#define MNX_X3_EPI32_V -1
-#endif
 
 #define CK(x)                                                                                     \
     do {                                                                                          \
@@ -91,9 +81,6 @@ __global__ void cmp_words(const unsigned* a, const unsigned* b, size_t n, unsign
     for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, bad);
 }
-#if MNX_X3_LAB & 16
-namespace mnx { hipError_t x3_lab_read_stamps(unsigned long long* host); }
-#endif
 
 struct Shape { const char* name; int epi, M, N, K; };
 
@@ -101,7 +88,8 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64;
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
     const char* only = (argc > 3 && strcmp(argv[3], "-")) ? argv[3] : nullptr;
-    const bool split = argc > 4 && !strcmp(argv[4], "fp16x3");
+    const bool two = argc > 4 && !strcmp(argv[4], "fp16x2");
+    const bool split = two || (argc > 4 && !strcmp(argv[4], "fp16x3"));
     // argv[5] = "stream": while the dispatched kernel is timed, a second stream copies 1 GiB blocks (HBM read + write) with
     // argv[6] workgroups (default 1024): does the GEMM share a bottleneck with plain HBM traffic?
     const bool bg = argc > 5 && !strcmp(argv[5], "stream");
@@ -130,8 +118,7 @@ int main(int argc, char** argv) {
     const bool zero = getenv("MNX_LAB_ZERO") && atoi(getenv("MNX_LAB_ZERO"));
     const bool nobase = getenv("MNX_LAB_NOBASE") && atoi(getenv("MNX_LAB_NOBASE"));
     if (getenv("MNX_LAB_CUS")) mnx::set_persistent_cus(atoi(getenv("MNX_LAB_CUS")));
-    printf("lab build: MNX_X3_LAB=%d MNX_X3_EPI32=%d, persistent workgroups %d%s\n", MNX_X3_LAB_V, MNX_X3_EPI32_V, mnx::persistent_cus(),
-           zero ? ", ZERO operands" : "");
+    printf("persistent workgroups %d%s\n", mnx::persistent_cus(), zero ? ", ZERO operands" : "");
     std::vector<Shape> shapes;
     const int L[4] = {9216, 2304, 576, 144}, C[4] = {128, 256, 512, 1024};
     static char names[64][32];
@@ -149,7 +136,7 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("images per group %d, %d launches per timing, operands %s\n", B, iters, split ? "fp16x3 (split, 3 MFMA terms; algorithmic TFLOP/s)" : "bf16");
+    printf("images per group %d, %d launches per timing, operands %s\n", B, iters, two ? "fp16x2 (split, 2 MFMA terms: activation lo plane dropped; algorithmic TFLOP/s)" : split ? "fp16x3 (split, 3 MFMA terms; algorithmic TFLOP/s)" : "bf16");
     printf("%-9s epi %8s %6s %6s | %10s %8s | %10s %8s %-6s| max |err| vs fp32 reference (base, disp)\n", "shape", "M", "N",
            "K", "base us", "TF", "disp us", "TF", "kernel");
     for (const Shape& sh : shapes) {
@@ -187,14 +174,17 @@ int main(int argc, char** argv) {
         CK(hipMemcpyAsync(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
         mnx::SplitArgs sp;
-        sp.a_lo = nA; sp.w_lo = nW; sp.c_lo = out16 ? nC : 0; sp.oscale = 1.0f; sp.terms = 3;
+        sp.a_lo = nA; sp.w_lo = nW; sp.c_lo = out16 ? nC : 0; sp.oscale = 1.0f; sp.terms = two ? 2 : 3;
+        if (two && sh.epi == 1) sp.c_planes = 1;          // fc1 -> fc2 on two terms: the hi plane only
+        double mhz0 = 0.0;
+        (void)mnx::x3_clock_read(&mhz0, true);
         auto launch = [&](int v) {
             const float* resid = sh.epi == 2 ? (const float*)Cc : nullptr;      // in-place residual, as the encoder runs it
             return v ? mnx::launch_gemm16(dt, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st, split ? &sp : nullptr)
                      : mnx::launch_gemm16_tile128(dt, sh.epi, A, W, Cc, bias, resid, sh.M, sh.N, sh.K, st, split ? &sp : nullptr);
         };
         double us[2] = {0, 0}, err[2] = {0, 0};
-        const size_t cbytes = nC * (out16 ? 2 * planes : 4);
+        const size_t cbytes = nC * (out16 ? 2 * (two && sh.epi == 1 ? 1 : planes) : 4);
         void* Cb = nullptr;                       // split modes: the 128x128 kernel's output, for the word-by-word comparison
         unsigned long long* dbad = nullptr;
         unsigned long long bad = 0;
@@ -250,32 +240,13 @@ int main(int argc, char** argv) {
         const double tol = out16 ? 2e-2 : 1e-3;
         printf("%-9s %3d %8d %6d %6d | %10.1f %8.1f | %10.1f %8.1f %-6s| %.2e %.2e%s", sh.name, sh.epi, sh.M, sh.N, sh.K, us[0],
                us[0] > 0 ? fl / us[0] / 1e6 : 0.0, us[1], fl / us[1] / 1e6,
-               mnx::gemm16_route(dt, sh.epi, sh.M, sh.N, sh.K, 3, true), err[0], err[1],
+               mnx::gemm16_route(dt, sh.epi, sh.M, sh.N, sh.K, two ? 2 : 3, true), err[0], err[1],
                (err[0] > tol || err[1] > tol) ? "  FAIL" : "");
-        if (split) printf(" | words differing from the 128x128 kernel: %llu of %zu%s", bad, cbytes / 4, bad ? (MNX_X3_LAB_V & 47 ? " (ablation)" : "  MISMATCH") : "");
+        if (split) printf(" | words differing from the 128x128 kernel: %llu of %zu%s", bad, cbytes / 4, bad ? "  MISMATCH" : "");
+        double mhz = 0.0;
+        (void)mnx::x3_clock_read(&mhz, true);
+        if (mhz > 0.0) printf(" | gemm256x3 shader clock %.0f MHz", mhz);
         printf("\n");
-#if MNX_X3_LAB & 16
-        {   // clock stamps of the LAST launch: per workgroup {shader cycles, 100 MHz ticks, ticks inside epilogue code, tiles} x 2 wave rows
-            std::vector<unsigned long long> hs(256 * 8);
-            CK(mnx::x3_lab_read_stamps(hs.data()));
-            const int g = mnx::persistent_cus();
-            std::vector<double> mhz, dur, epi;
-            for (int w = 0; w < g; ++w) {
-                const unsigned long long* o = hs.data() + w * 8;
-                if (!o[1]) continue;
-                mhz.push_back((double)o[0] / (double)o[1] * 100.0);
-                dur.push_back(o[1] * 0.01);
-                epi.push_back(o[3] ? o[2] * 0.01 / o[3] : 0.0);
-            }
-            if (!mhz.empty()) {
-                std::sort(mhz.begin(), mhz.end()); std::sort(dur.begin(), dur.end()); std::sort(epi.begin(), epi.end());
-                const size_t n = mhz.size();
-                printf("   stamps (%zu workgroups): shader clock MHz min / median / max %.0f / %.0f / %.0f; workgroup lifetime us %.1f / %.1f / %.1f;"
-                       " tile end -> epilogue code done, us per tile %.2f / %.2f / %.2f\n", n, mhz[0], mhz[n / 2], mhz[n - 1], dur[0], dur[n / 2],
-                       dur[n - 1], epi[0], epi[n / 2], epi[n - 1]);
-            }
-        }
-#endif
         if (split) { CK(hipFree(Cb)); CK(hipFree(dbad)); }
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(Cc)); CK(hipFree(resid0)); CK(hipFree(drows)); CK(hipFree(ref));
     }

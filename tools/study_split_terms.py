@@ -196,6 +196,17 @@ def round_sig(x, bits, fp16_range=False):
     return y
 
 
+def round_block(x, bits):
+    """Block fixed point along the LAST axis (the 32 channels of one key / value row of one head): the row shares a power-of-two
+    scale 2^e >= max |x| of the row, every element is an integer of `bits` bits (two's complement, round to nearest) times
+    2^(e - bits + 1). What a K / V cache row stored as int16 / int24 + one exponent byte keeps: absolute error <= 2^(e - bits)."""
+    amax = x.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    e = torch.floor(torch.log2(amax)) + 1.0                    # 2^e > amax
+    q = torch.exp2(e - (bits - 1))
+    lim = 2.0 ** (bits - 1)
+    return torch.clamp(torch.round(x / q), -lim, lim - 1) * q
+
+
 @torch.no_grad()
 def forced_decode(features, sd, ids, lens, cfg=DECODER_DEFAULT, kv=None):
     """oracle.decoder.greedy_decode's loop, teacher-forced along `ids` (rows stop at `lens`): per (row, step) the masked
@@ -269,7 +280,7 @@ def main():
                                                 "synthetic_checkpoint(1, stress=True) against tests/golden/pixels_stress")
     ap.add_argument("--ranges", action="store_true", help="print max |operand| per op class (fp16 range check)")
     ap.add_argument("--kv", default=None,
-                    help="K / V cache byte study instead of the operand schemes: comma list of bf16,fp16,bf16+8,fp16+8 — the decoder "
+                    help="K / V cache byte study instead of the operand schemes: comma list of bf16,fp16,bf16+8,fp16+8,int16b,int20b,int24b — the decoder "
                          "runs teacher-forced on the fp32 features with every cached key / value rounded to that format")
     ap.add_argument("--two", action="append", default=[],
                     help="repeatable: comma list of op classes that run on TWO terms (ah.wh + ah.wl: the activation's lo plane is "
@@ -306,10 +317,13 @@ def main():
     rows = []
     if args.kv:
         fmt = {"bf16": (8, False, 2), "fp16": (11, True, 2), "bf16+8": (16, False, 3), "fp16+8": (19, True, 3), "fp32": (24, False, 4)}
+        for b_ in (12, 16, 20, 24):      # block fixed point: int<b> per element + one exponent byte per 32-channel row
+            fmt[f"int{b_}b"] = (b_, None, b_ / 8 + 1 / 32)
         for name in args.kv.split(","):
             bits, rng, nbytes = fmt[name]
             t0 = time.time()
-            lp, fl = forced_decode(ref, ck["decoder"], ids, lens, kv=lambda t: round_sig(t, bits, rng))
+            rnd = (lambda t: round_block(t, bits)) if rng is None else (lambda t: round_sig(t, bits, rng))
+            lp, fl = forced_decode(ref, ck["decoder"], ids, lens, kv=rnd)
             fm = [float(margin[b, t]) for b, t in zip(*np.nonzero(fl & m))]
             rec = {"kv_format": name, "bytes_per_element": nbytes, "significant_bits": bits, "images": N,
                    "logp_max_err": float(np.abs(lp - lp_ref)[m].max()), "logp_rms_err": float(np.sqrt((((lp - lp_ref)[m]) ** 2).mean())),
