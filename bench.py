@@ -588,8 +588,9 @@ def main():
                               "avg_launch_us": round(ms * 1e3 / n, 2), "algorithmic_bytes_per_launch": round(byts / n)})
         rows_p, t_p = min(768, args.slots), 64
         self_ms, cross_ms = eng.probe_decode_attn(rows_p, t_p, 24)   # 4 cycles over the 6 layers' K/V: HBM, not Infinity Cache
-        for label, ms, byts in (("mnx::dec_attn_kernel, self-attention (fp32 K/V cache of the sequence)", self_ms, rows_p * 8 * (t_p + 1) * 256),
-                                ("mnx::dec_attn_kernel, cross-attention (fp32 projected memory K/V, 144 keys)", cross_ms, rows_p * 8 * 144 * 256)):
+        # a cached K / V row of 32 channels is 100 bytes (24-bit block fixed point: int16 hi + uint8 lo per element + one scale, csrc/kvq.h)
+        for label, ms, byts in (("mnx::dec_attn_kernel, self-attention (K/V cache of the sequence, 3 bytes per element + a scale per row)", self_ms, rows_p * 8 * (t_p + 1) * 200),
+                                ("mnx::dec_attn_kernel, cross-attention (projected memory K/V, 144 keys, 3 bytes per element + a scale per row)", cross_ms, rows_p * 8 * 144 * 200)):
             gbs = byts / (ms * 1e-3) / 1e9
             extra.append({"kernel": label, "bound": "hbm", "measured": f"isolated probe: {rows_p} rows at position {t_p}, launches cycle the 6 layers' K/V (> 256 MB per cycle)",
                           "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),

@@ -48,6 +48,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "dec_types.h"
+#include "kvq.h"
 
 namespace mnx {
 
@@ -72,13 +73,14 @@ struct FusedArgs {
     // between "weights arrived" and "weights usable", and the kernels' LDS drops from 80-125 KB to 10-40 KB.
     // dec_fa
     const float *wqkv, *bqkv, *wo;     // wqkv_t [256][768], wo_t [256][256]
-    float *kcache, *vcache;  // this layer's self K / V cache [slots, heads, T, 32]
+    char *kcache, *vcache;   // this layer's self K / V cache: (slot, head) blocks of Tq rows, 24-bit block fixed point (kvq.h)
+    int Tq, Sq;              // rows per block of the self cache / of the memory K / V
     float* qbuf;             // mid form: the scaled queries [rows, 256] handed from dec_ma_kernel to dec_mb_kernel
     const float *emb, *pe;
     // dec_fb
     const float *wq2, *bq2, *wo2;      // wq2_t, wo2_t [256][256]
-    const float* memk;       // this layer's memory keys: block b, head h at memk + b * mem_stride + h * S * 32; values S * 256 behind
-    long long mem_stride;
+    const char* memk;        // this layer's memory keys: memory block b, head h at memk + b * mem_stride + h * kvq_block_bytes(Sq);
+    long long mem_stride;    // the values heads * kvq_block_bytes(Sq) behind (bytes)
     int S;
     // dec_fc
     const float *w1, *b1, *w2;         // w1_t [256][dff], w2_t [dff][256]
@@ -355,23 +357,22 @@ __device__ __forceinline__ void slice_mfma_store(const float* in /*[R][STR]*/, c
 // before the workgroup waits for anything: key rt, and the first VP value rows of the thread's chain.
 template <int VP>
 struct AttnPre {
-    f32x4 k[8];
-    f32x4 v[VP];
+    KvqK k;              // key row rt as fetched (decoded after the wait)
+    KvqV v[VP];
 };
 
 template <int VP>
-__device__ __forceinline__ void attn_prefetch_k(AttnPre<VP>& pre, const float* Kb, int ncache) {
+__device__ __forceinline__ void attn_prefetch_k(AttnPre<VP>& pre, const char* Kb, int nkb, int ncache) {
     const int rt = threadIdx.x & 255;
     const int key = min(rt, ncache > 0 ? ncache - 1 : 0);   // clamped: always a row of the slot's cache, unused beyond ncache
-#pragma unroll
-    for (int i = 0; i < 8; ++i) pre.k[i] = ldg4(Kb + (size_t)key * 32 + i * 4);
+    kvq_fetch_k(pre.k, Kb, nkb, key);
 }
 template <int VP>
-__device__ __forceinline__ void attn_prefetch_v(AttnPre<VP>& pre, const float* Vb, int ncache) {
+__device__ __forceinline__ void attn_prefetch_v(AttnPre<VP>& pre, const char* Vb, int nkb, int ncache) {
     const int rt = threadIdx.x & 255, rw = rt >> 6, kg = (rt & 63) >> 3, dq = rt & 7;
     const int last = ncache > 0 ? ncache - 1 : 0;
 #pragma unroll
-    for (int i = 0; i < VP; ++i) pre.v[i] = ldg4(Vb + (size_t)min(rw * 8 + kg + 32 * i, last) * 32 + dq * 4);
+    for (int i = 0; i < VP; ++i) kvq_fetch_v(pre.v[i], Vb, nkb, min(rw * 8 + kg + 32 * i, last), dq);
 }
 
 struct AttnLds { float *qs, *ks, *vs, *ps, *cs, *redm, *reds, *po; };   // per-kernel LDS arrays, all [R][...]
@@ -380,7 +381,7 @@ struct AttnLds { float *qs, *ks, *vs, *ps, *cs, *redm, *reds, *po; };   // per-k
 // memory rows; 2: self-attention with every key / value in the cache, ncache = t + 1 (dec_mb_kernel: the row of this step
 // was appended by the launch before). 0 and 2 evaluate the same chains on the same numbers.
 template <int R, int MODE, int VP, int PS>
-__device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* Kb, const float* Vb, int ncache, const AttnLds& m,
+__device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const char* Kb, const char* Vb, int nkb, int ncache, const AttnLds& m,
                                           const FusedArgs& a) {
     constexpr bool CROSS = MODE == 1, NEWLDS = MODE == 0;
     const int rl = threadIdx.x >> 8, rt = threadIdx.x & 255, lane = rt & 63, rw = rt >> 6, kg = lane >> 3, dq = lane & 7;
@@ -390,6 +391,11 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(m.qs + rl * 32 + i * 4);
     constexpr int NJ = CROSS ? 1 : 2;        // keys per thread: the memory has <= PS_CROSS (< 256) rows
+    // the thread's second key row (rt + 256; rows past 256 cached keys only) is requested before the first one is multiplied —
+    // where there are registers for it (R = 4: 1024 threads, 128 registers each: fetched when it is needed)
+    constexpr bool K2_EARLY = R < 4;
+    KvqK k2;
+    if (K2_EARLY && NJ == 2 && ncache > 256) kvq_fetch_k(k2, Kb, nkb, min(rt + 256, ncache - 1));       // (uniform per row)
     float sc[NJ];
     float mx = -3.0e38f;
 #pragma unroll
@@ -397,18 +403,12 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
         const int key = rt + 256 * j;
         float s = -3.0e38f;
         if (key < ncache) {
-            if (j == 0) {
-                s = dot32(q, pre.k);
-            } else {
-                f32x4 kv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) kv[i] = ldg4(Kb + (size_t)key * 32 + i * 4);
-                s = dot32(q, kv);
-            }
+            if (!K2_EARLY && j == 1) kvq_fetch_k(k2, Kb, nkb, key);
+            s = kvq_dot32(q, j == 0 ? pre.k : k2);      // dot32 on the row's integers x its power-of-two scale (exact)
         } else if (NEWLDS && key == ncache) {
             f32x4 kv[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(m.ks + rl * 32 + i * 4);
+            for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(m.ks + rl * 32 + i * 4);   // this step's key, already rounded through kvq_quant
             s = dot32(q, kv);
         }
         sc[j] = s;
@@ -437,9 +437,10 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
     for (int i = 0; i < VP; ++i) {
         const int key = rw * 8 + kg + 32 * i;
         if (key < ncache) {
-            const float pk = ps[key];
+            const float pk = ps[key] * pre.v[i].sc;          // the row's scale folded into the probability (exact)
+            const f32x4 vv = kvq_decode_v(pre.v[i]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaf(pre.v[i][e], pk, o[e]);
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(vv[e], pk, o[e]);
         } else if (NEWLDS && key == ncache) {
             const f32x4 vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
             const float pk = ps[key];
@@ -450,9 +451,15 @@ __device__ __forceinline__ void attn_rows(const AttnPre<VP>& pre, const float* K
 #pragma unroll 8
     for (int key = rw * 8 + kg + 32 * VP; key < nkeys; key += 32) {
         f32x4 vv;
-        if (NEWLDS && key == ncache) vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
-        else vv = ldg4(Vb + (size_t)key * 32 + dq * 4);
-        const float pk = ps[key];
+        float pk = ps[key];
+        if (NEWLDS && key == ncache) {
+            vv = *(const f32x4*)(m.vs + rl * 32 + dq * 4);
+        } else {
+            KvqV vr;
+            kvq_fetch_v(vr, Vb, nkb, key, dq);
+            vv = kvq_decode_v(vr);
+            pk *= vr.sc;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaf(vv[e], pk, o[e]);
     }
@@ -524,13 +531,15 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
         const int c = u.valid ? u.n : 0;
         bload<32 * U::CPW>(bw, a.wqkv + (size_t)(32 * u.kc0) * 768 + (c >> 5) * 256 + 32 * h + (c & 31), 768);
     }
-    const float* Kb = a.kcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
-    const float* Vb = a.vcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
+    // (the four waves of a row share its slot: the block bases are wave-uniform = scalar registers)
+    const size_t blk_u = ((size_t)__builtin_amdgcn_readfirstlane(rv.x) * a.heads + h) * kvq_block_bytes(a.Tq);
+    const char* Kb = a.kcache + blk_u;
+    const char* Vb = a.vcache + blk_u;
     AttnPre<VP> pre;
-    attn_prefetch_k<VP>(pre, Kb, rv.y);
+    attn_prefetch_k<VP>(pre, Kb, a.Tq, rv.y);
     prologue_finish<R, EMB ? 0 : 16, EMB>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum, pr);
     FSTAMP(1);
-    attn_prefetch_v<VP>(pre, Vb, rv.y);
+    attn_prefetch_v<VP>(pre, Vb, a.Tq, rv.y);
     FSTAMP(2);
     __syncthreads();                                     // xs complete
     FSTAMP(3);
@@ -543,15 +552,26 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     for (int idx = tid; idx < R * 96; idx += 256 * R) {
         const int r = idx / 96, c = idx - r * 96, part = c >> 5, d = c & 31;
         const float v = red_get<96, R>(smem + Ld::red, r, c) + a.bqkv[part * 256 + 32 * h + d];
+        // 32 consecutive threads hold the 32 channels of one (row, q | k | v): R * 96 is a multiple of 32 and so is the stride,
+        // so the half-wave is never split by the loop bound
         if (part == 0) {
             smem[Ld::qs + r * 32 + d] = v * QSCALE;
         } else {
-            smem[(part == 1 ? Ld::ks : Ld::vs) + r * 32 + d] = v;
+            // this step's key / value row as the cache will hold it (kvq.h): rounded here, used from LDS by this tick and
+            // appended to the slot's cache for the ticks after this one — the same number in both places
+            float amax = fabsf(v);
+#pragma unroll
+            for (int o_ = 16; o_ > 0; o_ >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o_, 64));
+            int qi;
+            float scale;
+            kvq_quant(v, amax, qi, scale);
+            smem[(part == 1 ? Ld::ks : Ld::vs) + r * 32 + d] = kvq_value(qi, scale);
             const int row = row0 + r;
-            if (row < n_act) {                           // append to the slot's cache (for the ticks after this one)
+            if (row < n_act) {
                 const int4 rr = a.st->rowv[row];
-                float* cache = part == 1 ? a.kcache : a.vcache;
-                cache[(((size_t)rr.x * a.heads + h) * a.T + rr.y) * 32 + d] = v;
+                char* blk = (part == 1 ? a.kcache : a.vcache) + ((size_t)rr.x * a.heads + h) * kvq_block_bytes(a.Tq);
+                kvq_store1(blk, a.Tq, rr.y, d, qi);
+                if (d == 0) kvq_store_scale(blk, a.Tq, rr.y, scale);
             }
         }
     }
@@ -559,7 +579,7 @@ __global__ __launch_bounds__(256 * R) void dec_fa_kernel(FusedArgs a) {
     FSTAMP(6);
     const AttnLds m = {smem + Ld::qs, smem + Ld::ks, smem + Ld::vs, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm,
                        smem + Ld::reds, smem + Ld::po};
-    attn_rows<R, 0, VP, PS_SELF>(pre, Kb, Vb, rv.y, m, a);
+    attn_rows<R, 0, VP, PS_SELF>(pre, Kb, Vb, a.Tq, rv.y, m, a);
     if (R >= 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);   // 128 registers per thread: not earlier
     __syncthreads();
     FSTAMP(10);
@@ -625,13 +645,21 @@ __global__ __launch_bounds__(512) void dec_ma_kernel(FusedArgs a) {
         const int r = idx / 96, c = idx - r * 96, part = c >> 5, d = c & 31;
         const float v = red_get<96, R>(smem + Ld::red, r, c) + a.bqkv[part * 256 + 32 * h + d];
         const int row = row0 + r;
+        // (32 consecutive threads = the 32 channels of one (row, q | k | v); the shuffles below run before any lane leaves)
+        float amax = fabsf(v);
+#pragma unroll
+        for (int o_ = 16; o_ > 0; o_ >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o_, 64));
         if (row >= n_act) continue;
         if (part == 0) {
             a.qbuf[(size_t)row * 256 + 32 * h + d] = v * QSCALE;
         } else {
             const int4 rr = a.st->rowv[row];
-            float* cache = part == 1 ? a.kcache : a.vcache;
-            cache[(((size_t)rr.x * a.heads + h) * a.T + rr.y) * 32 + d] = v;
+            int qi;
+            float scale;
+            kvq_quant(v, amax, qi, scale);
+            char* blk = (part == 1 ? a.kcache : a.vcache) + ((size_t)rr.x * a.heads + h) * kvq_block_bytes(a.Tq);
+            kvq_store1(blk, a.Tq, rr.y, d, qi);
+            if (d == 0) kvq_store_scale(blk, a.Tq, rr.y, scale);
         }
     }
 }
@@ -647,21 +675,22 @@ __global__ __launch_bounds__(256 * R) void dec_mb_kernel(FusedArgs a) {
     const int4 rv = a.st->rowv[row0 + (tid >> 8)];       // {slot, t, prev_tok, rank}; dummy rows: slot 0, t 0
     const int n_act = a.st->n_active;
     const int nk = rv.y + 1;                             // keys of the row: positions 0 .. t
-    const float* Kb = a.kcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
-    const float* Vb = a.vcache + ((size_t)rv.x * a.heads + h) * a.T * 32;
+    const size_t blk_u = ((size_t)__builtin_amdgcn_readfirstlane(rv.x) * a.heads + h) * kvq_block_bytes(a.Tq);
+    const char* Kb = a.kcache + blk_u;
+    const char* Vb = a.vcache + blk_u;
     AttnPre<VP> pre;
-    attn_prefetch_k<VP>(pre, Kb, nk);
+    attn_prefetch_k<VP>(pre, Kb, a.Tq, nk);
     f32x4 qv = {0.f, 0.f, 0.f, 0.f};
     if (rt < 8) qv = ldg4(a.qbuf + (size_t)(row0 + (tid >> 8)) * 256 + 32 * h + rt * 4);
     float bo[32];                                        // the head's slice of wo_t, columns 64 wave + lane (waves 0..3)
     if (R < 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);
-    attn_prefetch_v<VP>(pre, Vb, nk);
+    attn_prefetch_v<VP>(pre, Vb, a.Tq, nk);
     if (row0 >= n_act) return;                           // a tile of dummy rows (uniform per workgroup)
     if (rt < 8) *(f32x4*)(smem + Ld::qs + (tid >> 8) * 32 + rt * 4) = qv;
     __syncthreads();
     const AttnLds m = {smem + Ld::qs, nullptr, nullptr, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm, smem + Ld::reds,
                        smem + Ld::po};
-    attn_rows<R, 2, VP, PS_SELF>(pre, Kb, Vb, nk, m, a);
+    attn_rows<R, 2, VP, PS_SELF>(pre, Kb, Vb, a.Tq, nk, m, a);
     if (R >= 4 && wave < 4) bload<32>(bo, a.wo + (size_t)(32 * h) * 256 + 64 * wave + lane, 256);   // 128 registers per thread: not earlier
     __syncthreads();
     slice_mfma_store<32, FHS, R>(smem + Ld::cs, bo, a.part_out + (size_t)h * a.part_stride, row0, n_act);
@@ -680,10 +709,10 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     const int h = a.xcd ? blockIdx.y : blockIdx.x;
     const int row0 = a.row_base + (a.xcd ? xcd_tile<R>(blockIdx.x, gridDim.x) : (int)blockIdx.y) * R;
     FSTAMP(0);
-    const int mb = a.st->row_mem[row0 + (tid >> 8)];
+    const int mb = __builtin_amdgcn_readfirstlane(a.st->row_mem[row0 + (tid >> 8)]);    // wave-uniform: scalar block bases
     const int n_act = a.st->n_active;
-    const float* Kb = a.memk + (size_t)mb * a.mem_stride + (size_t)h * a.S * 32;
-    const float* Vb = Kb + (size_t)a.S * 256;
+    const char* Kb = a.memk + (size_t)mb * a.mem_stride + (size_t)h * kvq_block_bytes(a.Sq);
+    const char* Vb = Kb + (size_t)a.heads * kvq_block_bytes(a.Sq);
     // requests in the order of need: stream + partials, the unit's weights, then the memory rows (nothing of this tick is
     // needed to ask for them, but whatever is requested first is waited for first)
     ProRegs<8> pr;
@@ -694,11 +723,11 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     float bw[32 * U::CPW];
     if (u.active) bload<32 * U::CPW>(bw, a.wq2 + (size_t)(32 * u.kc0) * 256 + 32 * h + (u.valid ? u.n : 0), 256);
     AttnPre<VP> pre;
-    attn_prefetch_k<VP>(pre, Kb, a.S);
-    if (R < 4) attn_prefetch_v<VP>(pre, Vb, a.S);
+    attn_prefetch_k<VP>(pre, Kb, a.Sq, a.S);
+    if (R < 4) attn_prefetch_v<VP>(pre, Vb, a.Sq, a.S);
     prologue_finish<R, 8, false>(a, row0, n_act, h == 0, smem + Ld::xs, smem + Ld::psum, pr);
     FSTAMP(1);
-    if (R >= 4) attn_prefetch_v<VP>(pre, Vb, a.S);      // 1024 threads = 128 registers each: the value rows wait for the prologue's registers
+    if (R >= 4) attn_prefetch_v<VP>(pre, Vb, a.Sq, a.S);      // 1024 threads = 128 registers each: the value rows wait for the prologue's registers
     FSTAMP(2);
     __syncthreads();
     FSTAMP(3);
@@ -716,7 +745,7 @@ __global__ __launch_bounds__(256 * R) void dec_fb_kernel(FusedArgs a) {
     FSTAMP(6);
     const AttnLds m = {smem + Ld::qs, nullptr, nullptr, smem + Ld::ps, smem + Ld::cs, smem + Ld::redm, smem + Ld::reds,
                        smem + Ld::po};
-    attn_rows<R, 1, VP, PS_CROSS>(pre, Kb, Vb, a.S, m, a);
+    attn_rows<R, 1, VP, PS_CROSS>(pre, Kb, Vb, a.Sq, a.S, m, a);
     __syncthreads();
     FSTAMP(10);
     slice_mfma_store<32, FHS, R>(smem + Ld::cs, bo, a.part_out + (size_t)h * a.part_stride, row0, n_act);
@@ -817,7 +846,9 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
     float* pb[2] = {b.fpart, b.fpart + (size_t)16 * b.fpart_rows * D};
     FusedArgs a = {};
     a.st = b.st; a.part_stride = b.fpart_rows * D; a.T = T; a.heads = H; a.emb = w.emb; a.pe = w.pe; a.S = b.S; a.dff = w.dff;
-    a.mem_stride = (long long)b.S * w.layers * 2 * D;
+    const size_t self_blk = kvq_block_bytes(b.Tq), mem_blk = kvq_block_bytes(b.Sq);
+    a.Tq = b.Tq; a.Sq = b.Sq;
+    a.mem_stride = (long long)((size_t)w.layers * 2 * H * mem_blk);
     a.stamps = g_stamps;
     a.row_base = row_base;
     a.xcd = (xcd && !mid && rows % 32 == 0) ? 1 : 0;
@@ -829,8 +860,8 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = l > 0 ? w.L[l - 1].b2 : nullptr;
         a.gamma = Lw.ln1_g; a.beta = Lw.ln1_b; a.wqkv = Lw.wqkv_t; a.bqkv = Lw.bqkv; a.wo = Lw.wo_t;
-        a.kcache = b.self_k + (size_t)l * b.slots * H * T * 32;
-        a.vcache = b.self_v + (size_t)l * b.slots * H * T * 32;
+        a.kcache = b.self_k + (size_t)l * b.slots * H * self_blk;
+        a.vcache = b.self_v + (size_t)l * b.slots * H * self_blk;
         const dim3 gab = a.xcd ? dim3(rows / R, H) : dim3(H, rows / R);
         if (mid) {      // the linear half on 16-row tiles, then the attention half on R-row tiles
             const dim3 gma(H, rows / MaLds::R);
@@ -844,7 +875,7 @@ static void fused_layers(const DecWeights& w, const DecBuffers& b, int row_base,
         a.stage = stage;
         a.xin = xb[stage & 1]; a.xout = xb[(stage + 1) & 1]; a.part_in = pb[(stage + 1) & 1]; a.part_out = pb[stage & 1];
         a.bias_in = Lw.bo; a.gamma = Lw.ln2_g; a.beta = Lw.ln2_b; a.wq2 = Lw.wq2_t; a.bq2 = Lw.bq2; a.wo2 = Lw.wo2_t;
-        a.memk = b.mem_kv + (size_t)l * 2 * b.S * D;
+        a.memk = b.mem_kv + (size_t)l * 2 * H * mem_blk;
         hipLaunchKernelGGL((dec_fb_kernel<R>), gab, dim3(256 * R), FbLds<R>::total * 4, s, a);
         ++stage;
         // ---- feed-forward block

@@ -69,9 +69,11 @@ struct DecBuffers {
     float *x2, *part;                          // the other residual-stream buffer [slots,256]; w_2 K-slice partials [dff/256][slots,256]
     float *fpart;                              // fused tick (dec_fused.hip): two alternating partial buffers [2][16][fpart_rows,256]
     int fpart_rows;                            // rows a plane holds = the largest capacity that runs fused / mid (<= slots)
-    float *self_k, *self_v;                    // [layers, slots, heads, T, 32]
+    char *self_k, *self_v;                     // [layers, slots, heads] blocks of Tq rows, 24-bit block fixed point (kvq.h)
     float *memory;                             // [32*S, 256]   scratch of one admission
-    float *mem_kv;                             // [mem_blocks, layers, K|V, heads, S, 32]
+    float *mem_kv32;                           // [32, layers, K|V, heads, S, 32] fp32 scratch of one admission (SGEMM output)
+    char *mem_kv;                              // [mem_blocks, layers, K|V, heads] blocks of Sq rows (kvq.h)
+    int Tq, Sq;                                // rows per block: T, S rounded up to a multiple of 4
     int* tokens;                               // [slots, T]
     float* logp;                               // [slots, T]
     float* hidden;                             // [slots, T, 256]
@@ -80,27 +82,33 @@ struct DecBuffers {
 };
 
 // ---- beam search (a12): hypotheses of image i live in slots i*K .. i*K+K-1 ------------------------------
+// Up to MAX_BEAM_IMGS images = several reference batches are searched in ONE step sequence (mnx_predict_beam): images are
+// independent but for the positional-encoding row, which is numbered inside each image's own reference batch
+// (BeamBuffers::ref_batch images).
+constexpr int MAX_BEAM_IMGS = 128;
 constexpr int MAX_BEAM = 8;
 constexpr int BEAM_LP_STRIDE = 256;   // floats per row of the masked log-prob buffer (vocab <= 256)
 constexpr int BEAM_ANC_MAX = 512;     // ancestry entries per hypothesis held in LDS (max_len + 1 <= 512)
 
 struct BeamState {
-    int top_fin[ROW_TILE];             // the image's top beam has finished at some step
-    int n_hyps[ROW_TILE];              // finished hypotheses seen so far (all of them, not only the kept ones)
-    int pool_n[ROW_TILE];              // kept hypotheses (<= n_best)
-    int order[ROW_TILE][MAX_BEAM];     // rank -> storage index of the kept hypotheses (score descending, stable)
-    float pscore[ROW_TILE][MAX_BEAM];  // by storage index
-    int plen[ROW_TILE][MAX_BEAM];
-    float cum[ROW_TILE * MAX_BEAM];    // cumulative log-prob of every live hypothesis (by slot)
+    int top_fin[MAX_BEAM_IMGS];             // the image's top beam has finished at some step
+    int n_hyps[MAX_BEAM_IMGS];              // finished hypotheses seen so far (all of them, not only the kept ones)
+    int pool_n[MAX_BEAM_IMGS];              // kept hypotheses (<= n_best)
+    int order[MAX_BEAM_IMGS][MAX_BEAM];     // rank -> storage index of the kept hypotheses (score descending, stable)
+    float pscore[MAX_BEAM_IMGS][MAX_BEAM];  // by storage index
+    int plen[MAX_BEAM_IMGS][MAX_BEAM];
+    float cum[MAX_BEAM_IMGS * MAX_BEAM];    // cumulative log-prob of every live hypothesis (by slot)
 };
 
 struct BeamBuffers {
     BeamState* bs;
     float* blp;      // [B*K, BEAM_LP_STRIDE] masked log-probs of the current step
     int* anc;        // [B*K, anc_stride]: slot that holds step tau of the hypothesis (K/V, hidden at tau; id at tau-1)
-    int* ptok;       // [32, MAX_BEAM, T] ids of the kept hypotheses
-    float* phid;     // [32, MAX_BEAM, T, 256] decoder outputs of the kept hypotheses, or null
+    int* ptok;       // [B, pool_stride, T] ids of the kept hypotheses
+    float* phid;     // [B, pool_stride, T, 256] decoder outputs of the kept hypotheses, or null
     int B, K, n_best, anc_stride;
+    int ref_batch;   // images per reference batch: image i belongs to batch i / ref_batch (the PE numbering unit); B <= 32: B
+    int pool_stride; // kept hypotheses stored per image (>= n_best)
 };
 
 // token classes for the on-device atom-position scan (CharTokenizer.sequence_to_smiles 'indices')
@@ -109,6 +117,8 @@ struct TokenClasses {
     int lbracket, rbracket, id_C, id_l, id_B, id_r, x0, y0, vocab;
 };
 
+// fp32 projected memory K / V of `n_blocks` (image, layer, K|V, head) blocks of S rows -> quantised blocks at dst (kvq.h)
+hipError_t kvq_pack_enqueue(const float* src, char* dst, int n_blocks, int S, int Sq, hipStream_t s);
 hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const int* rowc_dev, int n, int chunk_tag,
                              int mem_blk0, int max_len, int stop_on_eos, hipStream_t s);
 hipError_t dec_enqueue_reset(const DecBuffers& b, hipStream_t s);

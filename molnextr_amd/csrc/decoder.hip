@@ -12,6 +12,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "dec_types.h"
+#include "kvq.h"
 
 namespace mnx {
 
@@ -80,6 +81,35 @@ hipError_t launch_sgemm_tn(const float* A, const float* W, const float* bias, fl
     return hipGetLastError();
 }
 
+// The projected memory K / V of an admission (sgemm_tn_kernel's perm_S output: fp32 rows of 32 channels, [image][layer][K|V][head]
+// [position][32]) -> the quantised blocks the decode ticks read (kvq.h), once per image. 8 lanes per row, 16 bytes each.
+__global__ __launch_bounds__(256) void kvq_pack_kernel(const float* __restrict__ src, char* __restrict__ dst, long long n_rows,
+                                                       int S, int Sq) {
+    const long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int part = threadIdx.x & 7;
+    if (r >= n_rows) return;            // (whole 8-lane groups leave together)
+    const f32x4 v = *(const f32x4*)(src + r * 32 + part * 4);
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    int q[4];
+    float scale = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kvq_quant(v[u], amax, q[u], scale);
+    const long long blk_i = r / S;
+    const int key = (int)(r - blk_i * S);
+    char* blk = dst + (size_t)blk_i * kvq_block_bytes(Sq);
+    kvq_store4(blk, Sq, key, part * 4, q);
+    if (part == 0) kvq_store_scale(blk, Sq, key, scale);
+}
+
+hipError_t kvq_pack_enqueue(const float* src, char* dst, int n_blocks, int S, int Sq, hipStream_t s) {
+    const long long n_rows = (long long)n_blocks * S;
+    hipLaunchKernelGGL(kvq_pack_kernel, dim3((unsigned)((n_rows + 31) / 32)), dim3(256), 0, s, src, dst, n_rows, S, Sq);
+    return hipGetLastError();
+}
+
 // =============================================================================================
 // Decode tick. Rows are SLOTS (dec_types.h): up to 256 sequences resident at once, each at its own position t.
 // One tick advances every alive slot by one token:
@@ -112,8 +142,9 @@ struct LinArgs {
     const float* gamma;   // LN weight / bias (PRO 1, 2)
     const float* beta;
     float* out;           // EPI 1: x [slots, N] in place; EPI 2/3: [slots, N]; EPI 0: q buffer [slots, 256]
-    float* kcache;        // EPI 0: this layer's self K cache [slots, heads, T, 32]
-    float* vcache;
+    char* kcache;         // EPI 0: this layer's self K cache: (slot, head) blocks of Tq rows (kvq.h)
+    char* vcache;
+    int Tq;               // rows per block of the self cache = kvq_rows(T)
     float* x_write;       // PRO 2: residual stream x [slots, 256] written by column-block 0
     const float* emb;     // PRO 2: [V, 256]
     const float* pe;      // PRO 2: [pe_len, 256]
@@ -269,8 +300,19 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
         if (part_ == 0) {
             *(f32x4*)(a.out + (size_t)row * 256 + ch) = v * 0.17677669529663687f;   // q / sqrt(32) before QK^T (onmt MHA)
         } else {
-            float* cache = part_ == 1 ? a.kcache : a.vcache;
-            *(f32x4*)(cache + (((size_t)slot * a.heads + hd) * a.T + rv.y) * 32 + d) = v;
+            // this tile's 32 columns are the 32 channels of ONE head's key (or value) row: the 8 lanes of the row (part 0..7,
+            // consecutive lanes) agree on its max and append it to the slot's cache as 24-bit block fixed point (kvq.h)
+            float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+            int qv[4];
+            float scale = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kvq_quant(v[u], amax, qv[u], scale);
+            char* blk = (part_ == 1 ? a.kcache : a.vcache) + ((size_t)slot * a.heads + hd) * kvq_block_bytes(a.Tq);
+            kvq_store4(blk, a.Tq, rv.y, d, qv);
+            if (part == 0) kvq_store_scale(blk, a.Tq, rv.y, scale);
         }
     } else if (EPI == 1) {
         *(f32x4*)(a.out + (size_t)row * a.N + n) = res4 + v;
@@ -292,12 +334,12 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinArgs a) {
 // =============================================================================================
 struct AttnArgs {
     const float* q;      // [slots, 256] pre-scaled
-    const float* K;      // base of this layer's keys
-    const float* V;
+    const char* K;       // base of this layer's keys: blocks of nkb rows (kvq.h), block (owner, head) at owner * row_stride +
+    const char* V;       // head * head_stride BYTES; owner = the slot (self), the memory block (cross), an ancestor's slot (ANC)
     float* ctx;          // [slots, 256]
     const DecState* st;
-    long long row_stride, head_stride;   // floats
-    int kstride, fixed_keys, heads, cross;
+    long long row_stride, head_stride;   // bytes
+    int nkb, fixed_keys, heads, cross;
     const int* anc;      // ANC: [slots, anc_stride] slot that holds key tau of the hypothesis (beam search)
     int anc_stride;
     int row_base;        // first row of the tick branch
@@ -318,52 +360,46 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
     const int slot = rv.x;
     const int nkeys = a.cross ? a.fixed_keys : rv.y + 1;
     const long long rowb = a.cross ? (long long)a.st->row_mem[row] : (long long)slot;
-    const float* Kb = a.K + rowb * a.row_stride + hd * a.head_stride;
-    const float* Vb = a.V + rowb * a.row_stride + hd * a.head_stride;
+    const char* Kb = a.K + rowb * a.row_stride + hd * a.head_stride;
+    const char* Vb = a.V + rowb * a.row_stride + hd * a.head_stride;
     // P.V: wave w takes keys w*8 + kg + 32*i (kg = lane>>3), channel quad dq = lane&7: 32 keys per block-load. The first
     // VPRE block-loads (160 keys: all of the memory's 144, most self-attention rows) are requested HERE, before the keys: V does
     // not depend on the scores, and after the softmax the loop below paid two more dependent round trips (its unrolled body, then
     // its remainder) in a kernel that is five round trips long at the row counts where it is latency-bound (192-256 rows: one
-    // round of workgroups). Same operations in the same order: bit-identical.
+    // round of workgroups).
     constexpr int VPRE = 5;
     const int kg = lane >> 3, dq = lane & 7;
     const int nk32 = (nkeys + 31) & ~31;
-    f32x4 vpre[VPRE];
+    auto vblock = [&](int kk) {      // the block that holds value row kk (ANC: the hypothesis' own past lives in its ancestors' slots)
+        return ANC ? a.V + (long long)a.anc[(size_t)slot * a.anc_stride + kk] * a.row_stride + hd * a.head_stride : Vb;
+    };
+    KvqV vpre[VPRE];
 #pragma unroll
     for (int i = 0; i < VPRE; ++i) {
         const int key = wave * 8 + kg + 32 * i;
         const int kk = key < nkeys ? key : nkeys - 1;
-        const float* vp = Vb + (size_t)kk * a.kstride;
-        if (ANC)
-            vp = a.V + (long long)a.anc[(size_t)slot * a.anc_stride + kk] * a.row_stride + hd * a.head_stride +
-                 (size_t)kk * a.kstride;
-        vpre[i] = *(const f32x4*)(vp + dq * 4);
+        kvq_fetch_v(vpre[i], vblock(kk), a.nkb, kk, dq);
     }
     f32x4 q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = *(const f32x4*)(a.q + (size_t)row * 256 + hd * 32 + i * 4);
+    // both key rows of the thread (keys tid and tid + 256) are requested before either is multiplied (round 5 fetched the second
+    // after the first one's dot product: one more dependent round trip for rows past 256 keys); clamped addresses, no branch
+    KvqK kr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = tid + j * 256;
+        const int kk = key < nkeys ? key : nkeys - 1;
+        const char* kb = ANC ? a.K + (long long)a.anc[(size_t)slot * a.anc_stride + kk] * a.row_stride + hd * a.head_stride : Kb;
+        if (j == 0 || nkeys > 256) kvq_fetch_k(kr[j], kb, a.nkb, kk);      // (uniform per workgroup)
+    }
     float sc[2];
     float mx = -3.0e38f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int key = tid + j * 256;
         float s = -3.0e38f;
-        if (key < nkeys) {
-            const float* kp = Kb + (size_t)key * a.kstride;
-            if (ANC)   // the hypothesis' own past lives in the slots of its ancestors
-                kp = a.K + (long long)a.anc[(size_t)slot * a.anc_stride + key] * a.row_stride + hd * a.head_stride +
-                     (size_t)key * a.kstride;
-            f32x4 kv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) kv[i] = *(const f32x4*)(kp + i * 4);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s0 = fmaf(q[i][0], kv[i][0], s0); s1 = fmaf(q[i][1], kv[i][1], s1);
-                s2 = fmaf(q[i][2], kv[i][2], s2); s3 = fmaf(q[i][3], kv[i][3], s3);
-            }
-            s = (s0 + s1) + (s2 + s3);
-        }
+        if (key < nkeys) s = kvq_dot32(q, kr[j]);       // four fmaf chains on the row's integers x its power-of-two scale
         sc[j] = s;
         mx = fmaxf(mx, s);
     }
@@ -387,19 +423,18 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < VPRE; ++i)
         if (32 * i < nk32) {        // uniform: key = 32 i + (< 32)
-            const float p = ps[wave * 8 + kg + 32 * i];     // 0 for key >= nkeys
+            const float p = ps[wave * 8 + kg + 32 * i] * vpre[i].sc;     // 0 for key >= nkeys; the row's scale folded in (exact)
+            const f32x4 v = kvq_decode_v(vpre[i]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaf(vpre[i][e], p, o[e]);
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], p, o[e]);
         }
 #pragma unroll 4
     for (int key = wave * 8 + kg + 32 * VPRE; key < nk32; key += 32) {
         const int kk = key < nkeys ? key : nkeys - 1;
-        const float* vp = Vb + (size_t)kk * a.kstride;
-        if (ANC)
-            vp = a.V + (long long)a.anc[(size_t)slot * a.anc_stride + kk] * a.row_stride + hd * a.head_stride +
-                 (size_t)kk * a.kstride;
-        const f32x4 v = *(const f32x4*)(vp + dq * 4);
-        const float p = ps[key];        // 0 for key >= nkeys
+        KvqV vr;
+        kvq_fetch_v(vr, vblock(kk), a.nkb, kk, dq);
+        const float p = ps[key] * vr.sc;        // 0 for key >= nkeys
+        const f32x4 v = kvq_decode_v(vr);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], p, o[e]);
     }
@@ -767,14 +802,14 @@ hipError_t dec_enqueue_admit(const DecBuffers& b, const int* slots_dev, const in
     return hipGetLastError();
 }
 
-__global__ void beam_begin_kernel(DecState* st, int B, int K);
+__global__ void beam_begin_kernel(DecState* st, int B, int K, int ref_batch);
 __global__ void beam_pick_kernel(DecState* st, BeamBuffers bm, const float* hidden, int* etok, int T, int V, int eos);
 
 hipError_t dec_enqueue_tick(const DecWeights& w, const DecBuffers& b, int slots_scan, int rows, float* logits_trace,
                             int trace_rows, hipStream_t s, const BeamBuffers* beam, const int* forced, int fused_tile) {
     // slots_scan: state slots the begin kernel scans; rows: capacity of the compact active list this tick is
     // launched for (a multiple of 32, >= the number of alive slots — the host guarantees it)
-    if (beam) hipLaunchKernelGGL(beam_begin_kernel, dim3(1), dim3(256), 0, s, b.st, beam->B, beam->K);
+    if (beam) hipLaunchKernelGGL(beam_begin_kernel, dim3(1), dim3(256), 0, s, b.st, beam->B, beam->K, beam->ref_batch);
     else hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(BEGIN_THREADS), 0, s, b.st, slots_scan);
     return dec_enqueue_tick_rows(w, b, 0, rows, logits_trace, trace_rows, s, beam, forced, fused_tile);
 }
@@ -795,10 +830,11 @@ hipError_t dec_enqueue_tick_rows(const DecWeights& w, const DecBuffers& b, int r
     }
     for (int l = 0; l < (fused ? 0 : w.layers); ++l) {
         const DecLayerW& L = w.L[l];
-        float* kc = b.self_k + (size_t)l * b.slots * H * T * 32;
-        float* vc = b.self_v + (size_t)l * b.slots * H * T * 32;
+        const size_t self_blk = kvq_block_bytes(b.Tq), mem_blk = kvq_block_bytes(b.Sq);
+        char* kc = b.self_k + (size_t)l * b.slots * H * self_blk;
+        char* vc = b.self_v + (size_t)l * b.slots * H * self_blk;
         LinArgs a = {};
-        a.st = b.st; a.T = T; a.heads = H; a.row_base = row_base;
+        a.st = b.st; a.T = T; a.Tq = b.Tq; a.heads = H; a.row_base = row_base;
         // LN1 (+ embedding at layer 0) -> q, k, v
         // the residual stream alternates between two buffers: layer l > 0 sums (stream of layer l-1) + (its w_2 slices)
         // while it normalises them, and column-block 0 writes the sum to the other buffer for the rest of layer l
@@ -813,7 +849,7 @@ hipError_t dec_enqueue_tick_rows(const DecWeights& w, const DecBuffers& b, int r
         a.part = nullptr;
         AttnArgs at = {};
         at.q = b.q; at.K = kc; at.V = vc; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0; at.row_base = row_base;
-        at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32; at.fixed_keys = 0;
+        at.row_stride = (long long)(H * self_blk); at.head_stride = (long long)self_blk; at.nkb = b.Tq; at.fixed_keys = 0;
         if (beam) {
             at.anc = beam->anc; at.anc_stride = beam->anc_stride;
             hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(slots * H), dim3(256), 0, s, at);
@@ -827,9 +863,9 @@ hipError_t dec_enqueue_tick_rows(const DecWeights& w, const DecBuffers& b, int r
         a.in = xl; a.W = L.wq2; a.bias = L.bq2; a.gamma = L.ln2_g; a.beta = L.ln2_b; a.out = b.q;
         lin<1, 2>(s, a, slots);
         at.anc = nullptr;
-        at.K = b.mem_kv + (size_t)l * 2 * b.S * D;    // memory K/V: [block][layer][K|V][head][s][32]
-        at.V = at.K + (size_t)b.S * D;
-        at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = (long long)b.S * 32; at.kstride = 32;
+        at.K = b.mem_kv + (size_t)l * 2 * H * mem_blk;    // memory K/V: [memory block][layer][K|V][head] blocks of Sq rows
+        at.V = at.K + (size_t)H * mem_blk;
+        at.row_stride = (long long)((size_t)w.layers * 2 * H * mem_blk); at.head_stride = (long long)mem_blk; at.nkb = b.Sq;
         at.fixed_keys = b.S; at.cross = 1;
         hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(slots * H), dim3(256), 0, s, at);
         // context final_linear + residual
@@ -1050,10 +1086,11 @@ hipError_t dec_probe_attn(const DecWeights& w, const DecBuffers& b, int rows, in
     // Launch i reads the K/V of LAYER i % layers, as the six attention launches of a real tick do: the bytes touched
     // over one cycle (6 x 102 MB self at 768 rows / position 64, 6 x 226 MB cross) exceed the 256 MB Infinity Cache, so
     // the per-launch time is an HBM figure — re-launching one layer (round 2) measured the cache instead.
-    const size_t self_layer = (size_t)b.slots * H * T * 32;
+    const size_t self_blk = kvq_block_bytes(b.Tq), mem_blk = kvq_block_bytes(b.Sq);
+    const size_t self_layer = (size_t)b.slots * H * self_blk;
     AttnArgs at = {};
     at.q = b.q; at.ctx = b.ctx; at.st = b.st; at.heads = H; at.cross = 0;
-    at.row_stride = (long long)H * T * 32; at.head_stride = (long long)T * 32; at.kstride = 32;
+    at.row_stride = (long long)(H * self_blk); at.head_stride = (long long)self_blk; at.nkb = b.Tq;
     auto self_launch = [&](int i) {
         const int l = i % w.layers;
         at.K = b.self_k + (size_t)l * self_layer; at.V = b.self_v + (size_t)l * self_layer;
@@ -1063,10 +1100,11 @@ hipError_t dec_probe_attn(const DecWeights& w, const DecBuffers& b, int rows, in
     hipError_t e = hipEventRecord(ev[0], s);
     for (int i = 0; i < iters; ++i) self_launch(i);
     if (e == hipSuccess) e = hipEventRecord(ev[1], s);
-    at.row_stride = (long long)b.S * w.layers * 2 * D; at.head_stride = (long long)b.S * 32; at.fixed_keys = b.S; at.cross = 1;
+    at.row_stride = (long long)((size_t)w.layers * 2 * H * mem_blk); at.head_stride = (long long)mem_blk; at.nkb = b.Sq;
+    at.fixed_keys = b.S; at.cross = 1;
     auto cross_launch = [&](int i) {
         const int l = i % w.layers;
-        at.K = b.mem_kv + (size_t)l * 2 * b.S * D; at.V = at.K + (size_t)b.S * D;
+        at.K = b.mem_kv + (size_t)l * 2 * H * mem_blk; at.V = at.K + (size_t)H * mem_blk;
         hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(cap * H), dim3(256), 0, s, at);
     };
     for (int i = 0; i < w.layers; ++i) cross_launch(i);                                    // warm-up
@@ -1141,33 +1179,39 @@ namespace mnx {
 // The positional-encoding row is the row in the current (alive images x K) batch, as for greedy.
 // =============================================================================================
 __global__ void beam_init_kernel(DecState* st, BeamBuffers bm, int max_len, int sos) {
-    const int tid = threadIdx.x, n = bm.B * bm.K;
-    if (tid < n) {
-        st->alive[tid] = 1; st->t[tid] = 0; st->prev_tok[tid] = sos; st->len[tid] = 0;
-        st->chunk[tid] = 0; st->rowc[tid] = tid; st->rank[tid] = tid; st->mem_blk[tid] = tid / bm.K;
-        st->max_len[tid] = max_len; st->stop_on_eos[tid] = 1;
-        bm.bs->cum[tid] = (tid % bm.K == 0) ? 0.0f : -__builtin_inff();     // beam_search.py:43-45
-        bm.anc[(size_t)tid * bm.anc_stride] = tid;
+    const int n = bm.B * bm.K;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        st->alive[i] = 1; st->t[i] = 0; st->prev_tok[i] = sos; st->len[i] = 0;
+        st->chunk[i] = 0; st->rowc[i] = i; st->rank[i] = i; st->mem_blk[i] = i / bm.K;
+        st->max_len[i] = max_len; st->stop_on_eos[i] = 1;
+        bm.bs->cum[i] = (i % bm.K == 0) ? 0.0f : -__builtin_inff();     // beam_search.py:43-45
+        bm.anc[(size_t)i * bm.anc_stride] = i;
     }
-    if (tid < ROW_TILE) { bm.bs->top_fin[tid] = 0; bm.bs->n_hyps[tid] = 0; bm.bs->pool_n[tid] = 0; }
-    if (tid == 0) st->n_active = n;
+    for (int i = threadIdx.x; i < MAX_BEAM_IMGS; i += blockDim.x) { bm.bs->top_fin[i] = 0; bm.bs->n_hyps[i] = 0; bm.bs->pool_n[i] = 0; }
+    if (threadIdx.x == 0) st->n_active = n;
 }
 
-// rows of the step: alive images in index order x K; PE row = position in that batch
-__global__ void beam_begin_kernel(DecState* st, int B, int K) {
-    __shared__ int s_alive[ROW_TILE];
+// rows of the step: alive images in index order x K. PE row = position in the (alive images x K) batch of the image's OWN
+// reference batch (images [g ref_batch, (g + 1) ref_batch)): several reference batches share a step, none sees the others.
+__global__ void beam_begin_kernel(DecState* st, int B, int K, int ref_batch) {
+    __shared__ int s_alive[MAX_BEAM_IMGS];
+    __shared__ int s_before[MAX_BEAM_IMGS];       // alive images with a smaller index (all batches): the row order
     const int tid = threadIdx.x;
-    if (tid < ROW_TILE) s_alive[tid] = tid < B ? st->alive[tid * K] : 0;
+    for (int i = tid; i < MAX_BEAM_IMGS; i += blockDim.x) s_alive[i] = i < B ? st->alive[i * K] : 0;
     __syncthreads();
-    int total = 0;
-    for (int i = 0; i < B; ++i) total += s_alive[i];
-    if (tid < B * K) {
-        const int img = tid / K, j = tid % K;
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < B; ++i) { s_before[i] = run; run += s_alive[i]; }
+    }
+    __syncthreads();
+    const int total = B > 0 ? s_before[B - 1] + s_alive[B - 1] : 0;
+    for (int e = tid; e < B * K; e += blockDim.x) {
+        const int img = e / K, j = e % K;
         if (s_alive[img]) {
-            int r = 0;
-            for (int i = 0; i < img; ++i) r += s_alive[i];
-            st->rank[tid] = r * K + j;
-            st->active[r * K + j] = tid;
+            const int first = img / ref_batch * ref_batch;             // first image of this image's reference batch
+            const int r_in_batch = s_before[img] - s_before[first];
+            st->rank[e] = r_in_batch * K + j;
+            st->active[s_before[img] * K + j] = e;
         }
     }
     if (tid == 0) { st->n_active = total * K; st->chunk_alive[0] = total * K; st->tick = st->tick + 1; }
@@ -1287,7 +1331,7 @@ __global__ __launch_bounds__(256) void beam_pick_kernel(DecState* st, BeamBuffer
     __syncthreads();
     for (int q = 0; q < n_tasks; ++q) {            // materialise the kept hypotheses (ids + decoder outputs)
         const int i = task_src[q], parent = sel_idx[i] / V, tok = sel_idx[i] % V;
-        const size_t dst = ((size_t)img * MAX_BEAM + task_dst[q]) * T;
+        const size_t dst = ((size_t)img * bm.pool_stride + task_dst[q]) * T;
         for (int tau = tid; tau <= t; tau += 256)
             bm.ptok[dst + tau] = tau == t ? tok : etok[(size_t)lanc[parent][tau + 1] * T + tau];
         if (bm.phid)
@@ -1308,7 +1352,7 @@ __global__ void beam_gather_kernel(BeamBuffers bm, int T, int out_len, int* __re
     const int st = have ? bm.bs->order[img][r] : 0;
     const int n = have ? min(bm.bs->plen[img][st], out_len) : 0;
     if (tid == 0) { o_len[row] = n; o_scores[row] = have ? bm.bs->pscore[img][st] : -__builtin_inff(); }
-    const size_t src = ((size_t)img * MAX_BEAM + st) * T;
+    const size_t src = ((size_t)img * bm.pool_stride + st) * T;
     for (int i = tid; i < out_len; i += blockDim.x) o_tokens[row * out_len + i] = i < n ? bm.ptok[src + i] : 0;
     if (o_hidden && bm.phid)
         for (int i = tid; i < n * 64; i += blockDim.x)

@@ -16,6 +16,7 @@
 
 #include "dec_types.h"
 #include "kernels.h"
+#include "kvq.h"
 
 using namespace mnx;
 
@@ -604,11 +605,20 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     db.q = (float*)P.dalloc((size_t)SL * D * 4);
     db.ctx = (float*)P.dalloc((size_t)SL * D * 4);
     db.h = (float*)P.dalloc((size_t)SL * FF * 4);
-    const size_t cache = (size_t)c.dec_layers * SL * c.dec_heads * c.max_len * 32;
-    db.self_k = (float*)P.dalloc(cache * 4);
-    db.self_v = (float*)P.dalloc(cache * 4);
+    // self K / V and projected memory K / V: 24-bit block fixed point, 100 bytes per cached row of 32 channels (kvq.h)
+    db.Tq = kvq_rows(c.max_len); db.Sq = kvq_rows((int)S);
+    const size_t cache = (size_t)c.dec_layers * SL * c.dec_heads * kvq_block_bytes(db.Tq);
+    db.self_k = (char*)P.dalloc(cache);
+    db.self_v = (char*)P.dalloc(cache);
+    // every scale of a block must be finite before its first key is written (a lane whose key index is clamped may fetch a row
+    // beyond the written ones and multiplies a zero probability by its scale)
+    if (db.self_k && db.self_v && (hipMemset(db.self_k, 0, cache) != hipSuccess || hipMemset(db.self_v, 0, cache) != hipSuccess))
+        P.problems.push_back("hipMemset failed");
     db.memory = (float*)P.dalloc((size_t)ROW_TILE * S * D * 4);
-    db.mem_kv = (float*)P.dalloc((size_t)db.mem_blocks * S * c.dec_layers * 2 * D * 4);
+    db.mem_kv32 = (float*)P.dalloc((size_t)ROW_TILE * S * c.dec_layers * 2 * D * 4);
+    const size_t mem_bytes = (size_t)db.mem_blocks * c.dec_layers * 2 * c.dec_heads * kvq_block_bytes(db.Sq);
+    db.mem_kv = (char*)P.dalloc(mem_bytes);
+    if (db.mem_kv && hipMemset(db.mem_kv, 0, mem_bytes) != hipSuccess) P.problems.push_back("hipMemset failed");
     db.tokens = (int*)P.dalloc((size_t)SL * c.max_len * 4);
     db.logp = (float*)P.dalloc((size_t)SL * c.max_len * 4);
     db.hidden = (float*)P.dalloc((size_t)SL * c.max_len * D * 4);
@@ -920,7 +930,8 @@ static int decode_greedy_impl(mnx_engine* h, const float* features, int32_t B, c
     const int S = h->db.S, D = c.dec_dim;
     // enc_transform, then the cross-attention K/V of all layers in one SGEMM (memory block i = row i)
     HIPCHK(h, launch_sgemm_tn(features, h->dw.w_enc, h->dw.b_enc, h->db.memory, B * S, D, h->dw.enc_dim, s));
-    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s, S));
+    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv32, B * S, c.dec_layers * 2 * D, D, s, S));
+    HIPCHK(h, kvq_pack_enqueue(h->db.mem_kv32, h->db.mem_kv, B * c.dec_layers * 2 * c.dec_heads, S, h->db.Sq, s));
     HIPCHK(h, dec_enqueue_reset(h->db, s));
     HIPCHK(h, dec_enqueue_admit_rows(h->db, chunk_id, B, max_len, stop_on_eos, s));
     float* trace = nullptr;
@@ -979,26 +990,14 @@ int mnx_decode_forced(mnx_engine* h, const float* features, int32_t B, const int
                               logits_trace, stream);
 }
 
-int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t beam, int32_t n_best, int32_t max_len,
-                    int32_t* tokens, int32_t* lengths, float* scores, float* hidden, void* stream) {
-    if (!h) return MNX_ERR_INVALID_ARG;
-    if (!features || !tokens || !lengths || !scores || B < 1) {
-        h->err = "mnx_decode_beam: null/empty argument";
-        return MNX_ERR_INVALID_ARG;
-    }
+// Beam search over G reference batches in ONE step sequence: batch g = images [g ref_batch, (g + 1) ref_batch) of n_total
+// (features at feats[g]), every image K hypotheses, one row per hypothesis — G x ref_batch x K rows per step. Images are
+// independent; the positional-encoding rows are numbered inside each reference batch (beam_begin_kernel), so the result is
+// that of G separate searches. Outputs [n_total, n_best, ...].
+static int decode_beam_groups(mnx_engine* h, const float* const* feats, int G, int ref_batch, int n_total, int beam, int n_best,
+                              int max_len, int32_t* tokens, int32_t* lengths, float* scores, float* hidden, hipStream_t s) {
     const mnx_config& c = h->cfg;
-    if (B > ROW_TILE || beam < 1 || beam > MAX_BEAM || n_best < 1 || n_best > beam || max_len < 1 ||
-        max_len > c.max_len || c.max_len + 1 > BEAM_ANC_MAX || c.vocab > BEAM_LP_STRIDE) {
-        h->err = "mnx_decode_beam: B <= 32, 1 <= n_best <= beam <= 8, max_len <= cfg.max_len (<= 511) required";
-        return MNX_ERR_CAPACITY;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    HIPCHK(h, hipSetDevice(h->device));
-    if (!s) {
-        if (!h->own_stream) HIPCHK(h, hipStreamCreate(&h->own_stream));
-        s = h->own_stream;
-    }
-    const int S = h->db.S, D = c.dec_dim, T = h->db.T;
+    const int S = h->db.S, D = c.dec_dim, T = h->db.T, B = n_total;
     BeamBuffers& bm = h->beam;
     auto lazy = [&](void** p, size_t bytes) -> hipError_t {
         if (*p) return hipSuccess;
@@ -1006,16 +1005,25 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
         if (e == hipSuccess) { h->allocs.push_back(*p); h->bytes += bytes; }
         return e;
     };
+    // capacities: MAX_BEAM_IMGS images x MAX_BEAM hypotheses of state; 256 kept hypotheses (32 images x 8, or 128 x 2)
+    constexpr int POOL = ROW_TILE * MAX_BEAM;
+    const int pool_stride = std::min(MAX_BEAM, POOL / B);
+    if (pool_stride < n_best) { h->err = "beam search: n_best x images exceeds the hypothesis pool (256)"; return MNX_ERR_CAPACITY; }
     HIPCHK(h, lazy((void**)&bm.bs, sizeof(BeamState)));
-    HIPCHK(h, lazy((void**)&bm.blp, (size_t)ROW_TILE * MAX_BEAM * BEAM_LP_STRIDE * 4));
-    HIPCHK(h, lazy((void**)&bm.anc, (size_t)ROW_TILE * MAX_BEAM * (T + 1) * 4));
-    HIPCHK(h, lazy((void**)&bm.ptok, (size_t)ROW_TILE * MAX_BEAM * T * 4));
-    if (hidden) HIPCHK(h, lazy((void**)&bm.phid, (size_t)ROW_TILE * MAX_BEAM * T * D * 4));
-    bm.B = B; bm.K = beam; bm.n_best = n_best; bm.anc_stride = T + 1;
+    HIPCHK(h, lazy((void**)&bm.blp, (size_t)MAX_BEAM_IMGS * MAX_BEAM * BEAM_LP_STRIDE * 4));
+    HIPCHK(h, lazy((void**)&bm.anc, (size_t)MAX_BEAM_IMGS * MAX_BEAM * (T + 1) * 4));
+    HIPCHK(h, lazy((void**)&bm.ptok, (size_t)POOL * T * 4));
+    if (hidden) HIPCHK(h, lazy((void**)&bm.phid, (size_t)POOL * T * D * 4));
+    bm.B = B; bm.K = beam; bm.n_best = n_best; bm.anc_stride = T + 1; bm.ref_batch = ref_batch; bm.pool_stride = pool_stride;
     BeamBuffers run = bm;
     if (!hidden) run.phid = nullptr;
-    HIPCHK(h, launch_sgemm_tn(features, h->dw.w_enc, h->dw.b_enc, h->db.memory, B * S, D, h->dw.enc_dim, s));
-    HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv, B * S, c.dec_layers * 2 * D, D, s, S));
+    for (int g = 0; g < G; ++g) {      // enc_transform + memory K / V of batch g -> memory blocks g ref_batch ...
+        const int n = std::min(ref_batch, B - g * ref_batch);
+        char* memkv = h->db.mem_kv + (size_t)g * ref_batch * c.dec_layers * 2 * c.dec_heads * kvq_block_bytes(h->db.Sq);
+        HIPCHK(h, launch_sgemm_tn(feats[g], h->dw.w_enc, h->dw.b_enc, h->db.memory, n * S, D, h->dw.enc_dim, s));
+        HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv32, n * S, c.dec_layers * 2 * D, D, s, S));
+        HIPCHK(h, kvq_pack_enqueue(h->db.mem_kv32, memkv, n * c.dec_layers * 2 * c.dec_heads, S, h->db.Sq, s));
+    }
     HIPCHK(h, dec_enqueue_reset(h->db, s));
     HIPCHK(h, beam_enqueue_init(h->db, run, max_len, s));
     const int rows = (B * beam + ROW_TILE - 1) / ROW_TILE * ROW_TILE;
@@ -1059,6 +1067,28 @@ int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t bea
     return MNX_OK;
 }
 
+int mnx_decode_beam(mnx_engine* h, const float* features, int32_t B, int32_t beam, int32_t n_best, int32_t max_len,
+                    int32_t* tokens, int32_t* lengths, float* scores, float* hidden, void* stream) {
+    if (!h) return MNX_ERR_INVALID_ARG;
+    if (!features || !tokens || !lengths || !scores || B < 1) {
+        h->err = "mnx_decode_beam: null/empty argument";
+        return MNX_ERR_INVALID_ARG;
+    }
+    const mnx_config& c = h->cfg;
+    if (B > ROW_TILE || beam < 1 || beam > MAX_BEAM || n_best < 1 || n_best > beam || max_len < 1 ||
+        max_len > c.max_len || c.max_len + 1 > BEAM_ANC_MAX || c.vocab > BEAM_LP_STRIDE || B * beam > h->db.slots) {
+        h->err = "mnx_decode_beam: B <= 32, 1 <= n_best <= beam <= 8, max_len <= cfg.max_len (<= 511), B x beam <= dec_slots required";
+        return MNX_ERR_CAPACITY;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!s) {
+        if (!h->own_stream) HIPCHK(h, hipStreamCreate(&h->own_stream));
+        s = h->own_stream;
+    }
+    return decode_beam_groups(h, &features, 1, B, B, beam, n_best, max_len, tokens, lengths, scores, hidden, s);
+}
+
 int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t beam, int32_t max_len,
                      int32_t* tokens, int32_t* lengths, float* scores, int32_t* n_atoms, int32_t* atom_idx,
                      uint8_t* edges, int32_t kmax, void* stream) {
@@ -1070,8 +1100,10 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
     if (!h->have_tc) { h->err = "mnx_predict_beam: call mnx_set_token_classes first"; return MNX_ERR_INVALID_ARG; }
     const mnx_config& c = h->cfg;
     if (ref_batch < 1 || ref_batch > ROW_TILE || ref_batch > c.max_batch || beam < 1 || beam > MAX_BEAM || max_len < 1 ||
-        max_len > c.max_len || kmax < 1 || kmax > h->db.kmax) {
-        h->err = "mnx_predict_beam: ref_batch <= min(32, max_batch), beam <= 8, max_len <= cfg.max_len, kmax <= cfg.max_atoms required";
+        max_len > c.max_len || kmax < 1 || kmax > h->db.kmax || c.max_len + 1 > BEAM_ANC_MAX || c.vocab > BEAM_LP_STRIDE ||
+        ref_batch * beam > h->db.slots) {
+        h->err = "mnx_predict_beam: ref_batch <= min(32, max_batch), beam <= 8, max_len <= cfg.max_len (<= 511), kmax <= cfg.max_atoms, "
+                 "ref_batch x beam <= dec_slots required";
         return MNX_ERR_CAPACITY;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -1082,8 +1114,14 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
     }
     const int S = h->db.S, D = c.dec_dim;
     const size_t img_elems = (size_t)3 * c.img_size * c.img_size;
-    if (!h->beam_hidden) {      // decoder outputs along the winning hypothesis of one reference batch
-        const size_t bytes = (size_t)ROW_TILE * c.max_len * D * 4;
+    // Reference batches searched together (one step sequence, decode_beam_groups): up to MNX_BEAM_GROUPS (default 4) batches
+    // of one encoder launch group — a step of 4 x 160 rows costs 1.7x a step of 160 —, bounded by the state
+    // capacity (MAX_BEAM_IMGS images, dec_slots rows) and by the memory blocks
+    int g_max = 4;
+    if (const char* e = getenv("MNX_BEAM_GROUPS")) g_max = std::max(1, atoi(e));
+    g_max = std::max(1, std::min({g_max, MAX_BEAM_IMGS / ref_batch, h->db.slots / (ref_batch * beam), h->db.mem_blocks / ref_batch}));
+    if (!h->beam_hidden) {      // decoder outputs along the winning hypotheses of the reference batches of one search
+        const size_t bytes = (size_t)MAX_BEAM_IMGS * c.max_len * D * 4;
         HIPCHK(h, hipMalloc((void**)&h->beam_hidden, bytes));
         h->allocs.push_back(h->beam_hidden);
         h->bytes += bytes;
@@ -1101,9 +1139,9 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
     int fb_first[2] = {-1, -1}, fb_count[2] = {0, 0};
     bool feat_used[2] = {false, false};
     int next_enc = 0;
-    for (int ck = 0; ck < n_chunks; ++ck) {
+    for (int ck = 0; ck < n_chunks;) {
         // keep both feature buffers busy on the encoder stream: the encoder of the following groups runs while the
-        // beam search of this reference batch occupies the caller's stream
+        // beam search of these reference batches occupies the caller's stream
         for (int fb = 0; fb < 2; ++fb) {
             if (fb_first[fb] >= 0 || next_enc >= n_chunks) continue;
             const int cnt = std::min(grp, n_chunks - next_enc);
@@ -1118,21 +1156,28 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
         for (int i = 0; i < 2; ++i)
             if (fb_first[i] >= 0 && ck >= fb_first[i] && ck < fb_first[i] + fb_count[i]) fb = i;
         if (fb < 0) { h->err = "mnx_predict_beam: internal: reference batch without features"; return MNX_ERR_HIP; }
-        const int first = ck * ref_batch, n = std::min(ref_batch, n_img - first);
+        // the next G reference batches of this feature buffer, searched together
+        const int G = std::min(g_max, fb_first[fb] + fb_count[fb] - ck);
+        const int first = ck * ref_batch, n = std::min(G * ref_batch, n_img - first);
         HIPCHK(h, hipStreamWaitEvent(s, h->ev_enc_done[fb], 0));
-        const float* feats = h->feat_ring[fb] + (size_t)(ck - fb_first[fb]) * ref_batch * S * h->dw.enc_dim;
+        const float* feats[MAX_BEAM_IMGS];
+        for (int g = 0; g < G; ++g) feats[g] = h->feat_ring[fb] + (size_t)(ck + g - fb_first[fb]) * ref_batch * S * h->dw.enc_dim;
         int32_t* tok = tokens + (size_t)first * max_len;
-        int rc = mnx_decode_beam(h, feats, n, beam, 1, max_len, tok, lengths + first, scores + first, h->beam_hidden, s);
+        int rc = decode_beam_groups(h, feats, G, ref_batch, n, beam, 1, max_len, tok, lengths + first, scores + first, h->beam_hidden, s);
         if (rc != MNX_OK) return rc;
-        if (ck + 1 == fb_first[fb] + fb_count[fb]) {     // last reference batch of the group: the buffer is free again
+        ck += G;
+        if (ck == fb_first[fb] + fb_count[fb]) {     // last reference batch of the group: the buffer is free again
             HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
             feat_used[fb] = true;
             fb_first[fb] = -1;
         }
         int32_t* aidx = atom_idx + (size_t)first * kmax;
         HIPCHK(h, atoms_enqueue_raw(h->tc_dev, tok, lengths + first, n, max_len, kmax, aidx, n_atoms + first, s));
-        HIPCHK(h, edges_enqueue(h->dw, h->db, h->beam_hidden, nullptr, aidx, n_atoms + first, n, kmax, max_len,
-                                edges + (size_t)first * kmax * kmax, nullptr, s));
+        for (int o = 0; o < n; o += ROW_TILE) {      // the bond head's scratch holds one reference batch
+            const int nb = std::min(ROW_TILE, n - o);
+            HIPCHK(h, edges_enqueue(h->dw, h->db, h->beam_hidden + (size_t)o * max_len * D, nullptr, aidx + (size_t)o * kmax,
+                                    n_atoms + first + o, nb, kmax, max_len, edges + (size_t)(first + o) * kmax * kmax, nullptr, s));
+        }
     }
     HIPCHK(h, hipStreamSynchronize(s));
     return check_encoder_range(h, s);
@@ -1278,10 +1323,11 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
             free_tags.pop_back();
             for (int i = 0; i < n; ++i) ck.slots.push_back(ck.tag * ROW_TILE + i);
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_enc_done[fb], 0));   // already complete: ordering only
-            float* memkv = h->db.mem_kv + (size_t)ck.tag * ROW_TILE * S * c.dec_layers * 2 * D;
+            char* memkv = h->db.mem_kv + (size_t)ck.tag * ROW_TILE * c.dec_layers * 2 * c.dec_heads * kvq_block_bytes(h->db.Sq);
             const float* feats = h->feat_ring[fb] + (size_t)(next - fb_first[fb]) * ref_batch * S * h->dw.enc_dim;
             HIPCHK(h, launch_sgemm_tn(feats, h->dw.w_enc, h->dw.b_enc, h->db.memory, n * S, D, h->dw.enc_dim, s));
-            HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, memkv, n * S, c.dec_layers * 2 * D, D, s, S));
+            HIPCHK(h, launch_sgemm_tn(h->db.memory, h->dw.w_memkv, h->dw.b_memkv, h->db.mem_kv32, n * S, c.dec_layers * 2 * D, D, s, S));
+            HIPCHK(h, kvq_pack_enqueue(h->db.mem_kv32, memkv, n * c.dec_layers * 2 * c.dec_heads, S, h->db.Sq, s));
             if (next + 1 == fb_first[fb] + fb_count[fb]) {    // last reference batch of the group: buffer is free again
                 HIPCHK(h, hipEventRecord(h->ev_feat_free[fb], s));
                 feat_used[fb] = true;

@@ -271,9 +271,11 @@ def test_patch_embed_isa_requests_its_staging_loads_together_and_has_a_branch_fr
 
 def test_dec_attn_isa_has_its_value_rows_in_flight_before_it_waits_for_a_key(tmp_path):
     """dec_attn_kernel (decoder.hip): the first five value block-loads are requested ahead of the keys, so that the kernel's
-    first wait for vector memory has 5 value quads + 8 key quads outstanding (before: the values were fetched after the
-    softmax, two more dependent round trips); sgemm_tn_kernel: the next K slice's two loads sit between the two barriers of
-    the current slice (under its FMAs), not in front of the LDS stores."""
+    first wait for vector memory has 5 value quads (8 + 4 + 4 bytes each of the 24-bit block format, kvq.h) and the thread's
+    key row (6 x 16 bytes + its scale) outstanding (before: the values were fetched after the softmax, two more dependent
+    round trips), the second key row of rows past 256 keys behind ONE uniform branch in front of that wait too; the row is
+    decoded by one SDWA / byte convert per stored element; sgemm_tn_kernel: the next K slice's two loads sit between the two
+    barriers of the current slice (under its FMAs), not in front of the LDS stores."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -293,8 +295,12 @@ def test_dec_attn_isa_has_its_value_rows_in_flight_before_it_waits_for_a_key(tmp
         if "ILb1E" in name:     # beam search: the slot holding each key comes from the ancestry table (five entries first)
             assert len(re.findall(r"global_load_dword ", body[:first_wait])) >= 5, name
         else:
-            n = len(re.findall(r"global_load_dwordx4", body[:first_wait]))
-            assert n >= 13, (name, n)
+            head = body[:first_wait]
+            assert len(re.findall(r"global_load_dwordx2", head)) >= 5, name                  # value hi pieces
+            assert len(re.findall(r"global_load_dwordx4", head)) >= 12, name                 # two key rows: 4 hi + 2 lo pieces each
+            assert len(re.findall(r"global_load_dword ", head)) >= 5 * 2 + 2, name           # value lo pieces + scales, key scales
+            assert len(re.findall(r"s_cbranch", head)) <= 2, name
+            assert len(re.findall(r"v_cvt_f32_i32_sdwa", body)) >= 64 and len(re.findall(r"v_cvt_f32_ubyte", body)) >= 64, name
     sg = re.search(r"^_ZN3mnx15sgemm_tn_kernel\w+:[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M).group(1)
     loop = sg[sg.index("s_barrier"):]
     loop = loop[:loop.index("s_barrier", 10) + 9]              # first barrier .. second barrier of the K loop

@@ -786,6 +786,36 @@ def test_predict_beam_pipeline_equals_per_batch_beam(eng, dev):
         assert abs(x["beam_scores"][0] - y["beam_scores"][0]) < 1e-6
 
 
+def test_beam_search_of_several_reference_batches_in_one_step_sequence_equals_separate_searches(dev, synth_ckpt):
+    """mnx_predict_beam searches up to four reference batches of an encoder launch group in ONE step sequence (BASELINE config
+    5: 4 x 32 images x 5 hypotheses = 640 rows per step instead of 160). Images are independent but for the positional-encoding
+    row, which beam_begin_kernel numbers inside each image's own reference batch while rows of all batches share
+    the step — so the hypotheses must be EXACTLY those of separate searches: 112 images as reference batches of 32 (three
+    full, one ragged) through the pipeline with groups of 4 and of 2, against batch-by-batch mnx_decode_beam + host atom
+    positions + mnx_edges; beam 5 and beam 8 (8 x 32 x 4 = 1024 rows: the group count is capped by the slots)."""
+    from molnextr_amd.engine import Engine
+    from molnextr_amd.model import decode_batch, predict_pipeline
+    eng = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=128, dec_slots=1024)
+    try:
+        imgs = W.synthetic_images(112, first_index=500).to(dev)
+        for beam, max_len in ((5, 128), (8, 64)):
+            ref = []
+            for i in range(0, 112, 32):
+                ref += decode_batch(eng, eng.encode(imgs[i:i + 32].contiguous()), ref_batch_size=32, max_len=max_len, beam_size=beam)
+            for groups in ("4", "2", "1"):
+                os.environ["MNX_BEAM_GROUPS"] = groups
+                try:
+                    got = predict_pipeline(eng, imgs, ref_batch_size=32, max_len=max_len, beam_size=beam)
+                finally:
+                    os.environ.pop("MNX_BEAM_GROUPS", None)
+                assert len(got) == len(ref) == 112
+                for i, (x, y) in enumerate(zip(got, ref)):
+                    assert x["chartok_coords"] == y["chartok_coords"] and x["edges"] == y["edges"], (beam, groups, i)
+                    assert abs(x["beam_scores"][0] - y["beam_scores"][0]) < 1e-6, (beam, groups, i)
+    finally:
+        eng.close()
+
+
 def test_facade_uploads_the_next_group_while_the_engine_works(dev):
     """predict_images on host pages in several engine calls: group g+1 is uploaded (pinned staging) and transformed by
     mnx_preprocess on a side stream / helper thread while mnx_predict runs group g. The results must be those of the
