@@ -258,10 +258,10 @@ def library_sha16():
 
 def gemm_traffic(dtype, eb):
     """HBM bytes per encoder GEMM launch from the rocprofv3 --pmc passes of tools/gpu/profiles.sh (tools/collect_traffic.py writes
-    profiles/r05_gemm_traffic_<dtype>_b<images>.json and stamps it with the digest of the kernel sources it profiled). The
+    profiles/r06_gemm_traffic_<dtype>_b<images>.json and stamps it with the digest of the kernel sources it profiled). The
     counters cannot be collected inside a timed run, so the figure comes from a file — but only from one made with THESE
     kernels: (bytes, source) or (None, why not)."""
-    name = f"r05_gemm_traffic_{dtype}_b{eb}.json"
+    name = f"r06_gemm_traffic_{dtype}_b{eb}.json"
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, f"profiles/{name} not present (tools/gpu/profiles.sh makes it)"
@@ -385,7 +385,7 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--mode", default="pipeline", choices=["pipeline", "batch"])
-    ap.add_argument("--beam", type=int, default=1, help="beam size; > 1 times BASELINE config 5 (one batch at a time)")
+    ap.add_argument("--beam", type=int, default=1, help="beam size; > 1 times BASELINE config 5 through mnx_predict_beam")
     ap.add_argument("--max-len", type=int, default=480)
     ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["fp16x3", "fp16x3m", "bf16x3", "bf16", "fp16", "fp32"],
                     help="encoder operand mode. fp16x3 (default): three MFMA terms per product everywhere, fp32-class features (5e-6), "
@@ -612,12 +612,16 @@ def main():
             sub["fixed_T128"] = {"what": f"{ns} steps, every sequence decoded for exactly 128 tokens (EOS ignored): deterministic work",
                                  "molecules_per_s": round(ns * BATCH / t, 1), "tokens_per_s": round(ns * BATCH * 128 / t, 0)}
             if args.beam == 1:
-                x = images_for(0, 4)
+                nbm = min(16, max(1, eb // BATCH))
+                x = images_for(0, nbm)
                 process(eng, x[:BATCH].contiguous(), 1, "pipeline", beam=5, land=False)
-                t = timed(lambda: process(eng, x, 4, "pipeline", beam=5, land=False))
-                sub["beam5_batch32"] = {"what": "BASELINE config 5: beam 5 x batch 32 = 160 hypotheses per step, 4 reference batches through "
-                                                "mnx_predict_beam (batch by batch, the encoder running ahead on its own stream)",
-                                        "ms_per_batch": round(t / 4 * 1e3, 2), "molecules_per_s": round(4 * BATCH / t, 1),
+                t = timed(lambda: process(eng, x, nbm, "pipeline", beam=5, land=False))
+                sub["beam5_batch32"] = {"what": f"BASELINE config 5: beam 5 x batch 32 = 160 hypotheses per reference batch, {nbm} reference batches "
+                                                "through mnx_predict_beam: up to 8 reference batches of an encoder launch group share one step "
+                                                "sequence (1280 rows per step; positional-encoding rows numbered per reference batch, results "
+                                                "identical to batch-by-batch searches: tests/test_gpu_parity.py), the encoder running ahead on "
+                                                "its own stream",
+                                        "ms_per_batch": round(t / nbm * 1e3, 2), "molecules_per_s": round(nbm * BATCH / t, 1),
                                         "decoded_len_mean": round(float(np.mean(stats["lens"])), 1)}
             if args.dtype == "fp16x3" and args.beam == 1:
                 # the opt-in two-term mode on the SAME engine (same weights and kernels; mnx_set_op_terms switches the table)
@@ -650,8 +654,9 @@ def main():
         total = args.steps * BATCH * world
         if mode == "beam":
             workload = (f"BASELINE config 5: beam {args.beam} x batch 32 synthetic 384x384x3 images per GPU through mnx_predict_beam "
-                        "(reference batches searched one after the other, the encoder running ahead on its own stream): Swin-B "
-                        "encode + beam search (n_best 1) + atom positions + bond head on the best hypothesis")
+                        "(up to MNX_BEAM_GROUPS = 8 reference batches of an encoder launch group share one step sequence, the encoder "
+                        "running ahead on its own stream): Swin-B encode + beam search (n_best 1) + atom positions + bond head on the "
+                        "best hypothesis")
         else:
             workload = ("batch=32 synthetic 384x384x3 images per GPU, synthetic_checkpoint(0) in the reference state-dict "
                         f"layout (no pretrained weights offline), Swin-B encode ({args.dtype} operands) + greedy decode to EOS "

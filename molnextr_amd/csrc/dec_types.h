@@ -85,7 +85,7 @@ struct DecBuffers {
 // Up to MAX_BEAM_IMGS images = several reference batches are searched in ONE step sequence (mnx_predict_beam): images are
 // independent but for the positional-encoding row, which is numbered inside each image's own reference batch
 // (BeamBuffers::ref_batch images).
-constexpr int MAX_BEAM_IMGS = 128;
+constexpr int MAX_BEAM_IMGS = 256;
 constexpr int MAX_BEAM = 8;
 constexpr int BEAM_LP_STRIDE = 256;   // floats per row of the masked log-prob buffer (vocab <= 256)
 constexpr int BEAM_ANC_MAX = 512;     // ancestry entries per hypothesis held in LDS (max_len + 1 <= 512)

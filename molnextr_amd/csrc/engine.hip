@@ -336,13 +336,18 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     h->use_graph = !(ng && ng[0] == '1');
     // MNX_ENC_CUS=n (default 256): the encoder's persistent kernels (gemm256x3_kernel: one 150 KB-LDS workgroup per CU for the
     // length of a launch; window_attn_pipe_kernel: two) are launched on n workgroups (2 n), so that 256 - n CUs stay free for
-    // the decode stream's kernels while they run (co-residency without a CU mask). Process-wide.
-    if (const char* e = getenv("MNX_ENC_CUS")) {
-        const int n = atoi(e);
-        if (n < 64 || n > 256) {
-            g_create_error = "mnx_create: MNX_ENC_CUS must be 64..256";
-            delete h;
-            return MNX_ERR_INVALID_ARG;
+    // the decode stream's kernels while they run (DESIGN.md "co-residency": measured, not a win). The count is process-wide
+    // (gemm256.hip keeps it) and is set by EVERY mnx_create: an engine created without the variable restores 256, so that no
+    // engine inherits another one's value.
+    {
+        int n = 256;
+        if (const char* e = getenv("MNX_ENC_CUS")) {
+            n = atoi(e);
+            if (n < 64 || n > 256) {
+                g_create_error = "mnx_create: MNX_ENC_CUS must be 64..256";
+                delete h;
+                return MNX_ERR_INVALID_ARG;
+            }
         }
         set_persistent_cus(n);
     }
@@ -1005,7 +1010,7 @@ static int decode_beam_groups(mnx_engine* h, const float* const* feats, int G, i
         if (e == hipSuccess) { h->allocs.push_back(*p); h->bytes += bytes; }
         return e;
     };
-    // capacities: MAX_BEAM_IMGS images x MAX_BEAM hypotheses of state; 256 kept hypotheses (32 images x 8, or 128 x 2)
+    // capacities: MAX_BEAM_IMGS images x MAX_BEAM hypotheses of state; 256 kept hypotheses (32 images x 8 ... 256 x 1)
     constexpr int POOL = ROW_TILE * MAX_BEAM;
     const int pool_stride = std::min(MAX_BEAM, POOL / B);
     if (pool_stride < n_best) { h->err = "beam search: n_best x images exceeds the hypothesis pool (256)"; return MNX_ERR_CAPACITY; }
@@ -1114,10 +1119,10 @@ int mnx_predict_beam(mnx_engine* h, const float* images, int32_t n_img, int32_t 
     }
     const int S = h->db.S, D = c.dec_dim;
     const size_t img_elems = (size_t)3 * c.img_size * c.img_size;
-    // Reference batches searched together (one step sequence, decode_beam_groups): up to MNX_BEAM_GROUPS (default 4) batches
-    // of one encoder launch group — a step of 4 x 160 rows costs 1.7x a step of 160 —, bounded by the state
+    // Reference batches searched together (one step sequence, decode_beam_groups): up to MNX_BEAM_GROUPS (default 8) batches
+    // of one encoder launch group — a step of 4 x 160 rows costs 1.5x a step of 160 —, bounded by the state
     // capacity (MAX_BEAM_IMGS images, dec_slots rows) and by the memory blocks
-    int g_max = 4;
+    int g_max = 8;
     if (const char* e = getenv("MNX_BEAM_GROUPS")) g_max = std::max(1, atoi(e));
     g_max = std::max(1, std::min({g_max, MAX_BEAM_IMGS / ref_batch, h->db.slots / (ref_batch * beam), h->db.mem_blocks / ref_batch}));
     if (!h->beam_hidden) {      // decoder outputs along the winning hypotheses of the reference batches of one search

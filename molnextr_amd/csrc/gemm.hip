@@ -554,7 +554,9 @@ hipError_t launch_gemm16(int dtype, int epi, const void* A, const void* W, void*
                                      (char*)C + (size_t)r0 * N * (out16 ? es : sizeof(float)), bias,
                                      resid ? resid + (size_t)r0 * N : nullptr, M - r0, N, K, s, sp);
     }
-    // shape-only dispatch (never data- or environment-dependent): the persistent 256x256 kernel for the 16-bit-output
+    // shape-only dispatch (never data-dependent; the one environment input is the persistent workgroup count of MNX_ENC_CUS,
+    // which moves rows between gemm256x3_kernel and the 128x128 kernel — the two add the same numbers in the same order, so
+    // the results do not change: test_persistent_encoder_grids_on_fewer_cus_...): the persistent 256x256 kernel for the 16-bit-output
     // layers whose tile count fills the chip, the persistent 256x128 kernel for the fp32-output layers likewise, the
     // 128x128 kernel for everything else
     if (bias && gemm256_supports(dtype, epi, M, N, K)) return launch_gemm256(dtype, epi, A, W, C, bias, M, N, K, s, sp);

@@ -72,6 +72,11 @@ def dumps_field(obj) -> Optional[str]:
 PAD_TO_SQUARE_FILES = ("real/acs.csv", "real/UOB.csv")     # reference dataset.py:163-164
 
 
+class PeerFailed(RuntimeError):
+    """Raised by run_inference on the ranks that were fine when ANOTHER rank failed with an error that has no fallback
+    (capacity, I/O, a HIP error): every rank leaves together instead of waiting in the gather for a peer that is gone."""
+
+
 class RangeFallback(RuntimeError):
     """Raised by run_inference on EVERY rank when any rank's encoder left the fp16 range of the operand mode: the caller
     rebuilds its engine in the fallback mode (engine.RANGE_FALLBACK) and repeats the whole evaluation."""
@@ -96,8 +101,11 @@ def run_inference(engine, load_image: Callable[[int], np.ndarray], n_items: int,
     # repeat its shard in the fallback mode — one predictions table must not mix operand modes, and a rank that restarts
     # alone would leave its peers waiting in the gather —, so the ranks agree on "somebody saw a range error" (one scalar
     # all-reduce MAX) BEFORE the gather and raise together.
+    # ANY other failure of one rank (capacity, a missing image file, a HIP error) must not leave its peers in that collective
+    # either: the ranks exchange a status code — 0 ok, 1 range error, 2 fatal — and the fatal rank re-raises its own error
+    # after the exchange, the others raise PeerFailed.
     from .engine import MnxError, range_fallback_dtype
-    range_err = None
+    range_err, fatal = None, None
     try:
         for g0 in range(0, len(mine), step):
             ids = mine[g0:g0 + step]
@@ -107,10 +115,18 @@ def run_inference(engine, load_image: Callable[[int], np.ndarray], n_items: int,
                                                   out["edges"]))
     except MnxError as err:
         if range_fallback_dtype(err, getattr(engine, "dtype", None)) is None:
-            raise
-        range_err = err
-    seen = shard.any_rank(range_err is not None, dev) if world > 1 else range_err is not None
-    if seen:
+            fatal = err
+        else:
+            range_err = err
+    except BaseException as err:  # noqa: BLE001 - re-raised below, after the peers have been told
+        fatal = err
+    mine_status = 2 if fatal is not None else (1 if range_err is not None else 0)
+    status = shard.max_over_ranks(mine_status, dev) if world > 1 else mine_status
+    if fatal is not None:
+        raise fatal
+    if status == 2:
+        raise PeerFailed("another rank failed during inference; this rank leaves before the gather")
+    if status == 1:
         raise RangeFallback(str(range_err) if range_err is not None else "another rank's encoder left the fp16 operand range")
     rec = torch.cat(recs) if recs else torch.zeros(0, shard.record_words(kmax), dtype=torch.int32, device=dev)
     index = torch.tensor(mine, dtype=torch.int32, device=dev).view(-1, 1)

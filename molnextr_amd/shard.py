@@ -95,6 +95,16 @@ def gather_records(rec: torch.Tensor, force: bool = False) -> torch.Tensor:
     return out
 
 
+def max_over_ranks(value: int, device) -> int:
+    """The largest `value` of any rank (one scalar all-reduce MAX; the value itself without a process group): the ranks of
+    evaluate.run_inference agree on a status code with it before they enter the gather."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def any_rank(flag: bool, device) -> bool:
     """True on every rank when `flag` is true on at least one (one scalar all-reduce MAX; a plain bool without a process
     group). evaluate.run_inference uses it so that all ranks leave the fp16 operand mode together."""

@@ -174,3 +174,54 @@ def test_range_error_without_a_process_group_raises_rangefallback_and_other_erro
             raise MnxError("capacity", code=-5)
     with pytest.raises(MnxError, match="capacity"):
         E.run_inference(_Cap(), _page, 5, batch_size=2)
+
+
+# ---- any OTHER failure of one rank must not leave its peers waiting in a collective -------------------------
+class _CapEngine(_FakeEngine):
+    dtype = "fp16x3"
+
+    def __init__(self, fail):
+        super().__init__()
+        self.fail = fail
+
+    def predict(self, x, ref_batch=32, max_len=None):
+        if self.fail:
+            from molnextr_amd.engine import MnxError
+            raise MnxError("mnx_predict failed (-5): capacity", code=-5)
+        return super().predict(x, ref_batch, max_len)
+
+
+def _fatal_worker(rank, world, n, port, q):
+    import os
+    import torch.distributed as dist
+    from molnextr_amd.engine import MnxError
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    what = "returned"
+    try:
+        E.run_inference(_CapEngine(fail=(rank == 1)), _page, n, batch_size=2, rank=rank, world=world, group=8)
+    except MnxError as e:
+        what = f"own:{e}"
+    except E.PeerFailed:
+        what = "peer"
+    q.put((rank, what))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_fatal_error_on_one_rank_ends_every_rank_before_the_gather():
+    """Rank 1 fails with an error that has no fallback (capacity): it re-raises ITS error after telling its peer, rank 0 raises
+    PeerFailed instead of blocking in the status all-reduce / the all-gather for a rank that is gone."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35000 + (os.getpid() * 17) % 2000
+    procs = [ctx.Process(target=_fatal_worker, args=(r, 2, 7, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == "peer" and got[1].startswith("own:") and "capacity" in got[1]

@@ -787,28 +787,28 @@ def test_predict_beam_pipeline_equals_per_batch_beam(eng, dev):
 
 
 def test_beam_search_of_several_reference_batches_in_one_step_sequence_equals_separate_searches(dev, synth_ckpt):
-    """mnx_predict_beam searches up to four reference batches of an encoder launch group in ONE step sequence (BASELINE config
-    5: 4 x 32 images x 5 hypotheses = 640 rows per step instead of 160). Images are independent but for the positional-encoding
+    """mnx_predict_beam searches up to eight reference batches of an encoder launch group in ONE step sequence (BASELINE config
+    5: 8 x 32 images x 5 hypotheses = 1280 rows per step instead of 160). Images are independent but for the positional-encoding
     row, which beam_begin_kernel numbers inside each image's own reference batch while rows of all batches share
-    the step — so the hypotheses must be EXACTLY those of separate searches: 112 images as reference batches of 32 (three
-    full, one ragged) through the pipeline with groups of 4 and of 2, against batch-by-batch mnx_decode_beam + host atom
-    positions + mnx_edges; beam 5 and beam 8 (8 x 32 x 4 = 1024 rows: the group count is capped by the slots)."""
+    the step — so the hypotheses must be EXACTLY those of separate searches: 240 images as reference batches of 32 (seven
+    full, one ragged) through the pipeline with groups of 8, 3 and 1, against batch-by-batch mnx_decode_beam + host atom
+    positions + mnx_edges; beam 5 and beam 8 (8 x 32 x 5 = 1280 rows of capacity: at beam 8 the group count is capped by the slots)."""
     from molnextr_amd.engine import Engine
     from molnextr_amd.model import decode_batch, predict_pipeline
-    eng = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=128, dec_slots=1024)
+    eng = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=256, dec_slots=1280)
     try:
-        imgs = W.synthetic_images(112, first_index=500).to(dev)
+        imgs = W.synthetic_images(240, first_index=500).to(dev)
         for beam, max_len in ((5, 128), (8, 64)):
             ref = []
-            for i in range(0, 112, 32):
+            for i in range(0, 240, 32):
                 ref += decode_batch(eng, eng.encode(imgs[i:i + 32].contiguous()), ref_batch_size=32, max_len=max_len, beam_size=beam)
-            for groups in ("4", "2", "1"):
+            for groups in ("8", "3", "1"):
                 os.environ["MNX_BEAM_GROUPS"] = groups
                 try:
                     got = predict_pipeline(eng, imgs, ref_batch_size=32, max_len=max_len, beam_size=beam)
                 finally:
                     os.environ.pop("MNX_BEAM_GROUPS", None)
-                assert len(got) == len(ref) == 112
+                assert len(got) == len(ref) == 240
                 for i, (x, y) in enumerate(zip(got, ref)):
                     assert x["chartok_coords"] == y["chartok_coords"] and x["edges"] == y["edges"], (beam, groups, i)
                     assert abs(x["beam_scores"][0] - y["beam_scores"][0]) < 1e-6, (beam, groups, i)

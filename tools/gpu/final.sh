@@ -13,17 +13,20 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 bash tools/gpu/profiles.sh
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_full20.log 2>&1; echo "bench20 rc=$?"; tail -1 gpurun_out/bench_full20.log | cut -c1-300
 timeout 600 python bench.py --no-cpu-baseline --no-sub > gpurun_out/bench_default.log 2>&1; echo "bench default rc=$?"; tail -1 gpurun_out/bench_default.log | cut -c1-200
-for b in 448 512; do
-  timeout 600 tools/gemm_lab/lab $b 20 - fp16x3 > gpurun_out/r05_gemm_shapes_fp16x3_b$b.txt 2>&1; echo "lab $b rc=$?"
+timeout 600 python bench.py --no-cpu-baseline --no-sub --dtype fp16x3m > gpurun_out/bench_default_fp16x3m.log 2>&1; echo "bench default fp16x3m rc=$?"; tail -1 gpurun_out/bench_default_fp16x3m.log | cut -c1-200
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub --dtype fp16x3m > gpurun_out/bench20_fp16x3m.log 2>&1; echo "bench20 fp16x3m rc=$?"; tail -1 gpurun_out/bench20_fp16x3m.log | cut -c1-200
+timeout 600 python bench.py --gpus 1 --beam 5 --steps 32 --warmup 8 --no-cpu-baseline --no-sub > gpurun_out/bench_beam5.log 2>&1; echo "bench beam5 rc=$?"; tail -1 gpurun_out/bench_beam5.log | cut -c1-200
+for m in fp16x3 fp16x2; do
+  timeout 600 tools/gemm_lab/lab 512 20 - $m > gpurun_out/r06_gemm_shapes_${m}_b512.txt 2>&1; echo "lab $m rc=$?"
 done
-timeout 600 python tools/tick_time.py 64,128,192,256,384,512,640 unfused,fused 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_tick_time.txt; echo "tick_time rc=$?"
+timeout 600 python tools/tick_time.py 64,128,192,256,384,512,640 unfused,fused 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_tick_time.txt; echo "tick_time rc=$?"
 if [ -f tools/ab/libmolnextr_hip_stamps.so ]; then
   cp molnextr_amd/lib/libmolnextr_hip.so /tmp/mnx_cur.so
   cp tools/ab/libmolnextr_hip_stamps.so molnextr_amd/lib/libmolnextr_hip.so
   for cfg in "64 250 2 4" "128 250 4 4"; do
     set -- $cfg
     MNX_FUSED_STAMPS=/tmp/st_$1_$3.bin timeout 300 python tools/fused_stamps.py run $1 $2 $3 $4 2>&1 | grep -v amdgpu.ids
-    python tools/fused_stamps.py show /tmp/st_$1_$3.bin > gpurun_out/r05_fused_stamps_rows$1_tile$3.txt
+    python tools/fused_stamps.py show /tmp/st_$1_$3.bin > gpurun_out/r06_fused_stamps_rows$1_tile$3.txt
   done
   cp /tmp/mnx_cur.so molnextr_amd/lib/libmolnextr_hip.so
 fi

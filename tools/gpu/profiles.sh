@@ -17,11 +17,11 @@ echo "write rc=$?"
 cd $R
 F=$(find gpurun_out/pmc_fetch -name "*.db" | head -1); W=$(find gpurun_out/pmc_write -name "*.db" | head -1)
 # 99 GEMM layers per encode x 2 encodes
-python tools/collect_traffic.py $F $W gpurun_out/r05_gemm_traffic_${DT}_b$EB.json $EB 198
-cp gpurun_out/r05_gemm_traffic_${DT}_b$EB.json profiles/      # on this box: a bench run after this one reports it (same kernels)
+python tools/collect_traffic.py $F $W gpurun_out/r06_gemm_traffic_${DT}_b$EB.json $EB 198
+cp gpurun_out/r06_gemm_traffic_${DT}_b$EB.json profiles/      # on this box: a bench run after this one reports it (same kernels)
 DB=$(find gpurun_out/prof_stats -name "*.db" | head -1)
-python tools/rocpd_stats.py $DB gpurun_out/r05_kernel_stats_bench20.txt | head -14
-python tools/tick_profile.py $DB gpurun_out/r05_tick_profile_bench20.txt | head -12
-for f in $(find gpurun_out/prof_stats -name "*kernel_stats*.csv"); do cp $f gpurun_out/r05_rocprofv3_kernel_stats_bench20.csv; done
+python tools/rocpd_stats.py $DB gpurun_out/r06_kernel_stats_bench20.txt | head -14
+python tools/tick_profile.py $DB gpurun_out/r06_tick_profile_bench20.txt | head -12
+for f in $(find gpurun_out/prof_stats -name "*kernel_stats*.csv"); do cp $f gpurun_out/r06_rocprofv3_kernel_stats_bench20.csv; done
 rm -f $F $W $DB
 tail -1 gpurun_out/prof_stats.log | cut -c1-200
