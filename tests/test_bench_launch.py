@@ -175,10 +175,10 @@ def test_traffic_figure_is_only_taken_from_a_file_made_with_these_kernel_sources
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     monkeypatch.setattr(bench, "library_sha16", lambda: have)
     assert bench.gemm_traffic("fp16x3", 512)[0] is None                      # no file
-    (prof / "r05_gemm_traffic_fp16x3_b512.json").write_text(json.dumps({"hbm_bytes_per_launch": 123.4, "library_sha16": "0" * 16}))
+    (prof / "r06_gemm_traffic_fp16x3_b512.json").write_text(json.dumps({"hbm_bytes_per_launch": 123.4, "library_sha16": "0" * 16}))
     val, why = bench.gemm_traffic("fp16x3", 512)
     assert val is None and "refused" in why
-    (prof / "r05_gemm_traffic_fp16x3_b512.json").write_text(json.dumps({"hbm_bytes_per_launch": 123.4, "library_sha16": have}))
+    (prof / "r06_gemm_traffic_fp16x3_b512.json").write_text(json.dumps({"hbm_bytes_per_launch": 123.4, "library_sha16": have}))
     val, why = bench.gemm_traffic("fp16x3", 512)
     assert val == 123 and have in why
     # the collector computes the digest the same way (it is a script: run its digest lines on this tree)
