@@ -193,6 +193,40 @@ def test_gemm256x3_isa_has_no_scratch_and_only_its_own_m0_writes(tmp_path):
                             assert not (regs(nxt.split()[1].strip(",")) & data), (name, l, nxt)
                         ws += 1
                     k += 1
+            # the asm loads / stores take the tile's base from ONE SGPR pair per array, produced once in front of the
+            # epilogue's `s_nop 4` (gfx950 needs wait states between a SALU write of an SGPR and a vector-memory instruction that
+            # uses it as its address base; the hazard recognizer does not look into asm): no scalar instruction between the first
+            # and the last of these accesses may write a base register, and nothing may copy a load's destination before the
+            # counted wait has retired it (the compiler believes the asm's output is valid immediately)
+            mem = [i for i, l in enumerate(lines) if re.match(r"global_(load|store)_dwordx4 .*s\[\d+:\d+\]", l)]
+            # every copy of the epilogue starts at its `s_nop 4` (the bases are final there) and ends at its 32nd store
+            starts = [i for i, l in enumerate(lines) if l == "s_nop 4"]
+            assert len(starts) == len(st) // 32, (name, len(starts), len(st))
+            for s0 in starts:
+                k, n_st, bases = s0 + 1, 0, set()
+                while n_st < 32:
+                    l = lines[k]
+                    if re.match(r"global_(load|store)_dwordx4 .*s\[\d+:\d+\]", l):
+                        m = re.search(r"s\[(\d+):(\d+)\]", l)
+                        bases |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                        n_st += l.startswith("global_store")
+                    k += 1
+                for l in lines[s0 + 1:k]:
+                    if l.startswith("s_") and not l.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_setprio", "s_cbranch", "s_branch", "s_endpgm")):
+                        dst = l.split()[1].strip(",")
+                        m = re.match(r"s\[(\d+):(\d+)\]", dst)
+                        d = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else ({int(dst[1:])} if re.match(r"s\d+$", dst) else set())
+                        assert not (d & bases), (name, "a scalar instruction rewrites an asm address base inside the epilogue", l)
+            for i in mem:
+                if not lines[i].startswith("global_load_dwordx4"):
+                    continue
+                dest = regs(lines[i].split()[1].strip(","))
+                k = i + 1
+                while k < len(lines) and not lines[k].startswith("s_waitcnt vmcnt"):
+                    if lines[k].startswith(("v_mov", "v_accvgpr_write", "scratch_")):
+                        srcs = set().union(*[regs(t.strip(",")) for t in lines[k].split()[2:]]) if len(lines[k].split()) > 2 else set()
+                        assert not (srcs & dest), (name, "a load destination is copied before its wait", lines[i], lines[k])
+                    k += 1
     assert seen == ({("DF16b", e, 3, True) for e in range(4)} | {("DF16_", e, t, True) for e in range(4) for t in (2, 3)}
                     | {("DF16_", 1, t, False) for t in (2, 3)})
 
