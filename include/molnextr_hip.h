@@ -71,6 +71,7 @@ enum { MNX_OP_QKV = 1, MNX_OP_ATTN = 2, MNX_OP_PROJ = 4, MNX_OP_FC1 = 8, MNX_OP_
 /* FP16X3M's table: the two-term op classes of Swin-B's stages 1..4 (the patch-merging reduction BEHIND stage s counts as
  * stage s). tools/study_split_terms.py --two is the CPU emulation that picked it, tests/test_gpu_pixels.py the gate. */
 #define MNX_FP16X3M_TWO_TERM_BY_STAGE { 0, 0, MNX_OP_QKV | MNX_OP_FC1 | MNX_OP_FC2, 0 }
+#define MNX_FP16X3M_FIRST_BLOCK_BY_STAGE { 0, 0, 0, 0 }     /* first Swin block of the stage that runs the table (all: 0) */
 
 /* Architecture + capacity. Defaults of the reference inference config are in the comments
  * (MolNexTR/models/transformers.py:547-551 swin_base; MolNexTR/model.py:50-81; MolNexTR/utils.py:25). */
@@ -139,12 +140,13 @@ int mnx_set_encoder_tap(mnx_engine* h, int32_t item, float* dst);
 int mnx_set_split_terms(mnx_engine* h, int32_t mask);
 
 /* compute_dtype FP16X3 / FP16X3M only: the Linear op classes (MNX_OP_* bits, not MNX_OP_ATTN) of encoder stage `stage`
- * (0-based; -1 = every stage) that run on TWO terms (ah.wh + ah.wl). FP16X3 starts with none, FP16X3M with
- * MNX_FP16X3M_TWO_TERM_BY_STAGE; the weights are the same in both, so one engine can be measured under several tables
+ * (0-based; -1 = every stage) that run on TWO terms (ah.wh + ah.wl) in the Swin blocks first_block .. last_block of the stage
+ * (0-based, last_block may exceed the depth; the patch-merging reduction counts as the stage's last block). FP16X3 starts
+ * with none, FP16X3M with MNX_FP16X3M_TWO_TERM_BY_STAGE from MNX_FP16X3M_FIRST_BLOCK_BY_STAGE on; the weights are the same in both, so one engine can be measured under several tables
  * (tests/test_gpu_pixels.py; tools/study_split_terms.py is the CPU emulation). A 16-bit activation whose only consumer runs on
  * two terms is written as one plane. Takes effect at the next mnx_encode / mnx_predict call; not to be changed while one is
  * in flight. */
-int mnx_set_op_terms(mnx_engine* h, int32_t stage, int32_t two_term_mask);
+int mnx_set_op_terms(mnx_engine* h, int32_t stage, int32_t two_term_mask, int32_t first_block, int32_t last_block);
 
 /* Synchronises `stream` and reports (then clears) whether any mnx_encode since the last call produced a non-finite
  * feature row — the only way the fp16 operand modes can fail on a checkpoint whose activations exceed 65504. */

@@ -72,7 +72,10 @@ struct mnx_engine {
     size_t xn_lo = 0, qkv_lo = 0, attn_lo = 0, h_lo = 0;   // split modes: element offset of each buffer's lo plane
     int dt = 0;                                             // kernels.h MNX_DT_* the encoder kernels run (FP16X3M -> MNX_DT_F16X3)
     int split_mask = SPL_ALL;                               // op classes evaluated with their full term count (others: hi.hi only)
-    int two_mask[4] = {0, 0, 0, 0};                         // per stage: op classes whose full term count is TWO (ah.wh + ah.wl): FP16X3M, mnx_set_op_terms
+    // per stage: op classes whose full term count is TWO (ah.wh + ah.wl) in the blocks [two_first, two_last] of the stage (the
+    // patch-merging reduction counts as the stage's last block): FP16X3M, mnx_set_op_terms
+    int two_mask[4] = {0, 0, 0, 0};
+    int two_first[4] = {0, 0, 0, 0}, two_last[4] = {1 << 30, 1 << 30, 1 << 30, 1 << 30};
     int* enc_flag = nullptr;                                // device: set when the final LayerNorm sees a non-finite row
     float* zero_bias = nullptr;                             // [2 * widest C] zeros: the bias of the patch-merging reductions
     int zero_bias_n = 0;
@@ -330,7 +333,11 @@ int mnx_create(const mnx_config* cfg, const mnx_weight_desc* weights, int32_t n_
     if (cfg->compute_dtype == MNX_DTYPE_FP16X3M) {
         const int by_stage[4] = MNX_FP16X3M_TWO_TERM_BY_STAGE;
         // the table is written for Swin-B's four stages; a shallower encoder (the tests' tiny one) keeps its LAST stages' rows
-        for (int st = 0; st < cfg->n_stages; ++st) h->two_mask[st] = by_stage[st + 4 - cfg->n_stages];
+        const int first[4] = MNX_FP16X3M_FIRST_BLOCK_BY_STAGE;
+        for (int st = 0; st < cfg->n_stages; ++st) {
+            h->two_mask[st] = by_stage[st + 4 - cfg->n_stages];
+            h->two_first[st] = first[st + 4 - cfg->n_stages];
+        }
     }
     const char* ng = getenv("MNX_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
@@ -691,7 +698,7 @@ int mnx_set_split_terms(mnx_engine* h, int32_t mask) {
     return MNX_OK;
 }
 
-int mnx_set_op_terms(mnx_engine* h, int32_t stage, int32_t two_term_mask) {
+int mnx_set_op_terms(mnx_engine* h, int32_t stage, int32_t two_term_mask, int32_t first_block, int32_t last_block) {
     if (!h) return MNX_ERR_INVALID_ARG;
     if (h->dt != MNX_DT_F16X3) { h->err = "mnx_set_op_terms: compute_dtype must be FP16X3 or FP16X3M"; return MNX_ERR_INVALID_ARG; }
     if (stage < -1 || stage >= h->cfg.n_stages) { h->err = "mnx_set_op_terms: stage must be -1 (all) or 0..n_stages-1"; return MNX_ERR_INVALID_ARG; }
@@ -699,8 +706,9 @@ int mnx_set_op_terms(mnx_engine* h, int32_t stage, int32_t two_term_mask) {
         h->err = "mnx_set_op_terms: mask must be a subset of the Linear classes (1 qkv, 4 proj, 8 fc1, 16 fc2, 32 merge)";
         return MNX_ERR_INVALID_ARG;
     }
+    if (first_block < 0 || last_block < first_block) { h->err = "mnx_set_op_terms: 0 <= first_block <= last_block required"; return MNX_ERR_INVALID_ARG; }
     for (int st = 0; st < h->cfg.n_stages; ++st)
-        if (stage < 0 || stage == st) h->two_mask[st] = two_term_mask;
+        if (stage < 0 || stage == st) { h->two_mask[st] = two_term_mask; h->two_first[st] = first_block; h->two_last[st] = last_block; }
     return MNX_OK;
 }
 
@@ -775,8 +783,12 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
     // terms of an op class: its full count (3, or 2 for the classes of two_mask) or hi.hi alone. A 16-bit activation is
     // written as ONE plane when its consumer runs on two terms (planes_for): half the bytes out of the producer, half into
     // the consumer; the hi plane is the same bits either way.
-    int stage_now = 0;
-    auto terms_of = [&](int cls) { return !(h->split_mask & cls) ? 1 : (h->two_mask[stage_now] & cls) ? 2 : 3; };
+    int stage_now = 0, block_now = 0;
+    auto terms_of = [&](int cls) {
+        if (!(h->split_mask & cls)) return 1;
+        const bool in_range = block_now >= h->two_first[stage_now] && block_now <= h->two_last[stage_now];
+        return (in_range && (h->two_mask[stage_now] & cls)) ? 2 : 3;
+    };
     auto planes_for = [&](int consumer_cls) { return split && terms_of(consumer_cls) == 2 ? 1 : 2; };
     auto gemm = [&](int epi, const void* A, size_t a_lo, const W16& Wt, void* Cc, size_t c_lo, const float* bias,
                     const float* resid, int M, int N, int K, int cls, int c_planes = 2) -> hipError_t {
@@ -801,6 +813,7 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
         const int M = B * Hh * Ww;
         for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
             const BlockW& w = st.blocks[bi];
+            block_now = (int)bi;
             const int shift = (bi % 2 == 0) ? 0 : c.window / 2;   // reference transformers.py:363
             HIPCHK(h, ln(cur, w.ln1_g, w.ln1_b, h->xn16, nullptr, M, C, planes_for(SPL_QKV)));
             HIPCHK(h, gemm(EPI_BIAS_16, h->xn16, h->xn_lo, w.qkv_w, h->qkv16, h->qkv_lo, w.qkv_b, nullptr, M, 3 * C, C, SPL_QKV));
@@ -815,6 +828,7 @@ int mnx_encode(mnx_engine* h, const float* images, int32_t B, float* features_ou
             HIPCHK(h, tap((size_t)M * C));
         }
         if (si + 1 < c.n_stages) {
+            block_now = (int)st.blocks.size() - 1;        // the reduction behind the stage counts as its last block
             HIPCHK(h, launch_merge_ln16(dt, cur, st.m_g, st.m_b, h->xn16, B, Hh, Ww, C, 1e-5f, s, h->xn_lo, planes_for(SPL_MERGE)));
             HIPCHK(h, gemm(EPI_BIAS_F32, h->xn16, h->xn_lo, st.m_w, other, 0, h->zero_bias, nullptr, M / 4, 2 * C, 4 * C, SPL_MERGE));
             std::swap(cur, other);

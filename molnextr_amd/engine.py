@@ -35,6 +35,7 @@ SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mn
 DTYPES = {"bf16": 0, "fp16": 1, "fp32": 2, "bf16x3": 3, "fp16x3": 4, "fp16x3m": 5}
 DEFAULT_DTYPE = "fp16x3"
 SPLIT_CLASSES = {"qkv": 1, "attn": 2, "proj": 4, "fc1": 8, "fc2": 16, "merge": 32}
+FP16X3M_BLOCKS = {}                                       # {stage: (first_block, last_block)}: MNX_FP16X3M_FIRST_BLOCK_BY_STAGE
 FP16X3M_TWO_TERM = ("qkv.s2", "fc1.s2", "fc2.s2")       # include/molnextr_hip.h MNX_FP16X3M_TWO_TERM_BY_STAGE (tags: "cls" or "cls.sN", N 0-based)
 
 
@@ -101,7 +102,7 @@ def load_library():
     lib.mnx_set_split_terms.restype = C.c_int
     lib.mnx_set_split_terms.argtypes = [vp, i32]
     lib.mnx_set_op_terms.restype = C.c_int
-    lib.mnx_set_op_terms.argtypes = [vp, i32, i32]
+    lib.mnx_set_op_terms.argtypes = [vp, i32, i32, i32, i32]
     lib.mnx_encoder_status.restype = C.c_int
     lib.mnx_encoder_status.argtypes = [vp, C.POINTER(i32), vp]
     lib.mnx_decode_greedy.restype = C.c_int
@@ -257,12 +258,14 @@ class Engine:
         mask = 63 if three_term_classes is None else sum(SPLIT_CLASSES[c] for c in three_term_classes)
         self._check(self.lib.mnx_set_split_terms(self.h, mask), "mnx_set_split_terms")
 
-    def set_op_terms(self, two_term=None):
+    def set_op_terms(self, two_term=None, blocks=None):
         """fp16x3 / fp16x3m engines: the Linear op classes that run on TWO product terms (ah.wh + ah.wl), as tags "cls" (every
         stage) or "cls.sN" (encoder stage N, 0-based) with cls a name of SPLIT_CLASSES other than 'attn' — the syntax of
-        tools/study_split_terms.py --two. None = the mode's own table (fp16x3: none, fp16x3m: FP16X3M_TWO_TERM)."""
+        tools/study_split_terms.py --two. blocks: {stage: (first_block, last_block)} restricts a stage's table to those Swin
+        blocks (default: all of them). None = the mode's own table (fp16x3: none, fp16x3m: FP16X3M_TWO_TERM / _BLOCKS)."""
         if two_term is None:
             two_term = FP16X3M_TWO_TERM if self.dtype == "fp16x3m" else ()
+            blocks = FP16X3M_BLOCKS if self.dtype == "fp16x3m" and blocks is None else blocks
         n = len(self.enc.depths)
         masks = [0] * n
         for tag in two_term:
@@ -270,7 +273,8 @@ class Engine:
             for i in ([int(st)] if st else range(n)):
                 masks[i] |= SPLIT_CLASSES[cls]
         for i, m in enumerate(masks):
-            self._check(self.lib.mnx_set_op_terms(self.h, i, m), "mnx_set_op_terms")
+            lo, hi = (blocks or {}).get(i, (0, 1 << 30))
+            self._check(self.lib.mnx_set_op_terms(self.h, i, m, lo, hi), "mnx_set_op_terms")
 
     def encoder_nonfinite(self) -> bool:
         """Synchronises and reports (then clears) whether an encode since the last call produced non-finite features

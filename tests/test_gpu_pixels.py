@@ -397,6 +397,12 @@ TWO_TERM_TABLES = {
     "stages 3+4: qkv fc1 fc2": ("qkv.s2", "fc1.s2", "fc2.s2", "qkv.s3", "fc1.s3", "fc2.s3"),
     "stages 3+4: qkv proj fc1 fc2": ("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2", "qkv.s3", "proj.s3", "fc1.s3", "fc2.s3"),
     "every Linear of every stage": ("qkv", "proj", "fc1", "fc2", "merge"),
+    # a table restricted to a block range of the stage: (tags, {stage: (first_block, last_block)})
+    "stage 3 blocks 9-17: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (9, 17)}),
+    "stage 3 blocks 0-8: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (0, 8)}),
+    "stage 3 blocks 6-17: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (6, 17)}),
+    "stage 3 blocks 9-17: qkv proj fc1 fc2": (("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2"), {2: (9, 17)}),
+    "stage 3 blocks 12-17: qkv proj fc1 fc2": (("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2"), {2: (12, 17)}),
 }
 
 
@@ -409,7 +415,7 @@ def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, 
     5e-4 and raw logits within 6e-4 everywhere (measured 1.8e-4 / 4.96e-4; north_star: 1e-3) — and for every table 0 flips (the
     record shows what each costs: no table of useful size leaves the raw logits under 5e-4 with margin, so the mode is opt-in).
     The CPU emulation of the same tables: profiles/r06_two_term_study*.json."""
-    from molnextr_amd.engine import Engine, FP16X3M_TWO_TERM
+    from molnextr_amd.engine import Engine, FP16X3M_BLOCKS, FP16X3M_TWO_TERM
     dev = torch.device("cuda:0")
     gs = dict(np.load(os.path.join(golden_dir, "pixels_stress.npz")))
     stress_ck = W.synthetic_checkpoint(1, stress=True)
@@ -429,12 +435,12 @@ def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, 
             return {"logit_max_err_steps0_3": logit_err, "logp_max_err": err, "flips": len(flips), "steps": steps}
 
         for name, table in TWO_TERM_TABLES.items():
-            tags = FP16X3M_TWO_TERM if table is None else table
+            tags, blocks = (FP16X3M_TWO_TERM, FP16X3M_BLOCKS) if table is None else (table if isinstance(table[1], dict) else (table, {}))
             for e in (mol, pln, st):
-                e.set_op_terms(tags)
+                e.set_op_terms(tags, blocks)
             feats = mol.encode(x)
             f = feats.cpu().numpy()[:, ::9, ::16]
-            r = {"two_term": list(tags), "e2e": {"feature_max_err": float(np.abs(f - gold["feat_strided"]).max()),
+            r = {"two_term": list(tags), "blocks": {str(k): list(v) for k, v in blocks.items()}, "e2e": {"feature_max_err": float(np.abs(f - gold["feat_strided"]).max()),
                                                  "feature_rms_err": float(np.sqrt(((f - gold["feat_strided"]) ** 2).mean()))}}
             for case, n, max_len, is_mol in CASES:
                 r["e2e"][case] = measure(mol if is_mol else pln, feats, gold, case, n, max_len)
@@ -451,7 +457,7 @@ def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, 
         again = mol.encode(x)
         eng2 = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dtype="fp16x3m", dec_slots=64)
         try:
-            mol.set_op_terms(FP16X3M_TWO_TERM)
+            mol.set_op_terms(FP16X3M_TWO_TERM, FP16X3M_BLOCKS)
             assert torch.equal(eng2.encode(x), mol.encode(x)), "FP16X3M == FP16X3 + its table (same weights, same kernels)"
         finally:
             eng2.close()
