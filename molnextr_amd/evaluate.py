@@ -194,7 +194,7 @@ def main(argv=None):
     import pandas as pd
     import torch.distributed as dist
     from . import weights as W
-    from .engine import DTYPES, Engine
+    from .engine import DEFAULT_DTYPE, DTYPES, Engine
     from .preprocess import load_image_rgb
     ap = argparse.ArgumentParser(description="MolNexTR test-set inference on MI355X (reference main.py --do_test)")
     ap.add_argument("--data_path", default=".")
@@ -204,13 +204,14 @@ def main(argv=None):
                     help="checkpoint: reference .pth or .safetensors; 'synthetic' = deterministic test weights")
     ap.add_argument("--batch_size", type=int, default=4, help="per-GPU batch size; inference uses twice that")
     ap.add_argument("--dtype", default=None, choices=sorted(DTYPES),
-                    help="encoder operand mode; default fp16x3 (every token / atom / bond as the reference's fp32 path)")
+                    help="encoder operand mode; default engine.DEFAULT_DTYPE = fp16x3m (every token / atom / bond as the reference's fp32 path; "
+                         "fp16x3 = three product terms in every layer)")
     ap.add_argument("--fp16", action="store_true",
                     help="the reference's flag (main.py:40, exps/eval.sh: fp16 autocast): without --dtype it selects the one-plane "
                          "fp16 operand mode, which stays closer to the fp32 result than the reference's autocast path does "
                          "(tests/test_gpu_pixels.py, tests/golden/pixels_autocast_fp16.json)")
     args = ap.parse_args(argv)
-    dtype = args.dtype or ("fp16" if args.fp16 else "fp16x3")
+    dtype = args.dtype or ("fp16" if args.fp16 else DEFAULT_DTYPE)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

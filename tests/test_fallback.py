@@ -6,12 +6,13 @@ import warnings
 import pytest
 
 from molnextr_amd import model as M
-from molnextr_amd.engine import MNX_ERR_RANGE, MnxError, range_fallback_dtype
+from molnextr_amd.engine import DEFAULT_DTYPE, MNX_ERR_RANGE, MnxError, range_fallback_dtype
 
 
 def test_fallback_decision():
     rng = MnxError("mnx_predict failed (-6): non-finite features", code=MNX_ERR_RANGE)
     assert range_fallback_dtype(rng, "fp16x3") == "bf16x3"
+    assert DEFAULT_DTYPE == "fp16x3m" and range_fallback_dtype(rng, DEFAULT_DTYPE) == "bf16x3"
     assert range_fallback_dtype(rng, "fp16") == "bf16"
     assert range_fallback_dtype(rng, "bf16x3") is None and range_fallback_dtype(rng, "fp32") is None
     assert range_fallback_dtype(MnxError("capacity", code=-5), "fp16x3") is None

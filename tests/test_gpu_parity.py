@@ -32,7 +32,7 @@ def dev():
 @pytest.fixture(scope="module")
 def eng(synth_ckpt, dev):
     from molnextr_amd.engine import Engine
-    e = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32)
+    e = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dtype="fp16x3")
     yield e
     e.close()
 
@@ -383,7 +383,7 @@ def _engine_with_tick(synth_ckpt, tile, tile_ff=4, fused_max=128, slots=128, bra
     old = {k: os.environ.get(k) for k in keys}
     os.environ.update(keys)
     try:
-        return Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=slots)
+        return Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=slots, dtype="fp16x3")
     finally:
         for k, v in old.items():
             if v is None:
@@ -459,7 +459,7 @@ def test_persistent_encoder_grids_on_fewer_cus_give_identical_predictions(eng, d
     try:
         for n in (224, 192):
             os.environ["MNX_ENC_CUS"] = str(n)
-            e = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=96, dec_slots=128)
+            e = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=96, dec_slots=128, dtype="fp16x3")
             try:
                 assert torch.equal(e.encode(imgs[:32].contiguous()).cpu(), fwant), f"features differ bitwise at {n} workgroups"
                 _same_predictions(want, {k: v.cpu() for k, v in e.predict(imgs, ref_batch=32).items()})
@@ -467,10 +467,10 @@ def test_persistent_encoder_grids_on_fewer_cus_give_identical_predictions(eng, d
                 e.close()
         with pytest.raises(Exception, match="MNX_ENC_CUS"):
             os.environ["MNX_ENC_CUS"] = "32"
-            Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=64)
+            Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=64, dtype="fp16x3")
     finally:
         os.environ["MNX_ENC_CUS"] = "256"
-        Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=64).close()
+        Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=32, dec_slots=64, dtype="fp16x3").close()
         if old is None:
             os.environ.pop("MNX_ENC_CUS", None)
         else:
@@ -638,7 +638,7 @@ def test_grouped_encode_gives_identical_predictions(eng, dev, synth_ckpt):
     from molnextr_amd.engine import Engine
     imgs = W.synthetic_images(88, first_index=200).to(dev)       # reference batches of 16: 5 full + one of 8
     a = eng.predict(imgs, ref_batch=16)
-    big = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=64)
+    big = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=64, dtype="fp16x3")
     try:
         b = big.predict(imgs, ref_batch=16)
         c = big.predict(imgs[:40].contiguous(), ref_batch=32)   # group of one full + one ragged reference batch
@@ -795,7 +795,7 @@ def test_beam_search_of_several_reference_batches_in_one_step_sequence_equals_se
     positions + mnx_edges; beam 5 and beam 8 (8 x 32 x 5 = 1280 rows of capacity: at beam 8 the group count is capped by the slots)."""
     from molnextr_amd.engine import Engine
     from molnextr_amd.model import decode_batch, predict_pipeline
-    eng = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=256, dec_slots=1280)
+    eng = Engine(synth_ckpt["encoder"], synth_ckpt["decoder"], device=0, max_batch=256, dec_slots=1280, dtype="fp16x3")
     try:
         imgs = W.synthetic_images(240, first_index=500).to(dev)
         for beam, max_len in ((5, 128), (8, 64)):
@@ -927,10 +927,10 @@ def test_reference_format_checkpoint_loads_through_public_api(dev, tmp_path):
 
 def test_facade_falls_back_to_the_bf16_split_mode_when_fp16_overflows(dev, tmp_path):
     """A checkpoint the reference runs without complaint but whose MLP hidden state leaves the fp16 range (fc1 of one block
-    x 3e5, its fc2 x 1 / 3e5: activations ~1e6): the default fp16x3 engine reports MNX_ERR_RANGE; the facade must warn,
+    x 3e5, its fc2 x 1 / 3e5: activations ~1e6): an fp16x3 engine (and the default fp16x3m one) reports MNX_ERR_RANGE; the facade must warn,
     rebuild in bf16x3 (fp32 exponent range) and return what the fp32 oracle returns — not raise. A later call on a sane
     input must not inherit the flag (it is per call)."""
-    from molnextr_amd.engine import Engine, MnxError, MNX_ERR_RANGE
+    from molnextr_amd.engine import DEFAULT_DTYPE, Engine, MnxError, MNX_ERR_RANGE
     from molnextr_amd.model import molnextr, predict_pipeline
     from molnextr_amd.tokenizer import get_tokenizer
     from oracle.decoder import greedy_decode
@@ -944,7 +944,7 @@ def test_facade_falls_back_to_the_bf16_split_mode_when_fp16_overflows(dev, tmp_p
     torch.save({"encoder": ck["encoder"], "decoder": ck["decoder"], "args": ck["args"]}, src)
     imgs = W.synthetic_images(3, first_index=40)
     # the engine alone reports the range error, with its code
-    e = Engine(ck["encoder"], ck["decoder"], device=0, max_batch=4, dec_slots=64)
+    e = Engine(ck["encoder"], ck["decoder"], device=0, max_batch=4, dec_slots=64, dtype="fp16x3")
     try:
         with pytest.raises(MnxError) as ei:
             e.predict(imgs.to(dev), ref_batch=3)
@@ -953,7 +953,7 @@ def test_facade_falls_back_to_the_bf16_split_mode_when_fp16_overflows(dev, tmp_p
         e.close()
     m = molnextr(src, dev, max_batch=4)
     try:
-        assert m.engine.dtype == "fp16x3"
+        assert m.engine.dtype == DEFAULT_DTYPE == "fp16x3m"
         with pytest.warns(RuntimeWarning, match="bf16x3"):
             preds = m._with_fallback(lambda eng: predict_pipeline(eng, imgs.to(dev), m.tokenizer, ref_batch_size=3))
         assert m.engine.dtype == "bf16x3"

@@ -4,14 +4,15 @@
 
 Nothing of the GPU's output is handed to the checker. Per encoder operand mode:
 
-  * EXACT modes — `fp16x3` (split fp16 operands, three MFMA terms per product: the default of the facade and of bench.py)
-    and `fp32` (exact-fp32 MFMA): logits of steps 0..3 and the log-prob of every emitted token within 1e-3 (north_star's
+  * EXACT modes — `fp16x3` (split fp16 operands, three MFMA terms per product) and `fp32` (exact-fp32 MFMA): logits of steps 0..3 and the log-prob of every emitted token within 1e-3 (north_star's
     tolerance), every token id, length, atom position, coordinate and bond class EXACT for all 32 + 6 images,
     molecule-like and plain-random decoder, free-running AND teacher-forced;
-  * `fp16x3m` (fp16x3 with the Linears of engine.FP16X3M_TWO_TERM on TWO terms — the activation's lo plane dropped; opt-in):
-    the exact-mode assertions unchanged (0 flips over every teacher-forced step, every free-running row and every molecule
-    exact, both checkpoints), log-probs within 5e-4 (measured 1.8e-4) and raw logits within 6e-4 (measured 4.96e-4: the
-    round-5 review's 5e-4 gate for a DEFAULT mode is met without margin, which is why the mode stays opt-in);
+  * `fp16x3m` (fp16x3 with the Linears of engine.FP16X3M_TWO_TERM on TWO terms — the activation's lo plane dropped; the
+    DEFAULT of the engine, the facade and bench.py since round 6): the exact-mode assertions unchanged (0 flips over every
+    teacher-forced step, every free-running row and every molecule exact, both checkpoints), log-probs AND raw logits within
+    5e-4 — the round-5 review's gate for a default mode, half of north_star's 1e-3 (measured 1.8e-4 / 5.0e-4: the gate is met,
+    with no margin on the raw logits; the numbers are deterministic — the encoder is bit-reproducible and a one-tile decode
+    always takes the same tick form);
   * `bf16x3` (split bf16 operands): the same logit gate (1e-3); token flips are allowed only where the teacher-forced
     trace proves a near-tie (below);
   * `fp16` / `bf16` (one 16-bit plane per operand, the fastest modes): measured, with gates at 2x the values committed in
@@ -41,9 +42,9 @@ CASES = [("m6", 6, 480, True), ("m32", 32, 480, True), ("p6", 6, 64, False), ("p
 EXACT_MODES = ("fp32", "fp16x3", "fp16x3m")
 # max |logit error| over steps 0..3 and max |log-prob error| along the reference trajectory; max |feature error| (features
 # have unit rms). Exact modes and bf16x3: north_star's 1e-3. 16-bit modes: 2x the measured values (profiles/r03_pixels_parity.json).
-# fp16x3m: raw logits 6e-4 (measured 4.96e-4, profiles/r06_two_term_tables_gpu.json), log-probs 5e-4 (LOGP_TOL; measured 1.8e-4),
+# fp16x3m: raw logits and log-probs 5e-4 = the gate for a default mode (measured 4.997e-4 / 1.8e-4, profiles/r06_two_term_tables_gpu.json),
 # features 2x the CPU emulation's 1.3e-3 max (profiles/r06_two_term_study*.json).
-LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 6e-4, "bf16x3": 1e-3, "fp16": 2e-2, "bf16": 1.2e-1}
+LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 5e-4, "bf16x3": 1e-3, "fp16": 2e-2, "bf16": 1.2e-1}
 LOGP_TOL = dict(LOGIT_TOL, fp16x3m=5e-4)
 FEAT_TOL = {"fp32": 5e-5, "fp16x3": 5e-5, "fp16x3m": 2.6e-3, "bf16x3": 3e-4, "fp16": 7e-3, "bf16": 4.5e-2}
 FLIP_MARGIN_FACTOR = 2.0
@@ -223,7 +224,7 @@ def test_path_from_pixels_vs_reference(mode, gold, images, synth_ckpt):
 # largest operands it sees: 499 into fc1, 183 into fc2, 79 in the residual stream — far from the fp16 limit)
 # fp16x3m: 2x the emulation's --two fc1,fc2 row (profiles/r06_two_term_study_stress.json: max 9.0e-3 — the outlier channels —, rms 4.2e-4)
 STRESS_FEAT_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16x3m": 1.8e-2, "bf16x3": 1.2e-3}
-STRESS_LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 6e-4, "bf16x3": 1e-3}
+STRESS_LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 5e-4, "bf16x3": 1e-3}
 STRESS_LOGP_TOL = dict(STRESS_LOGIT_TOL, fp16x3m=5e-4)
 
 
@@ -403,6 +404,14 @@ TWO_TERM_TABLES = {
     "stage 3 blocks 6-17: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (6, 17)}),
     "stage 3 blocks 9-17: qkv proj fc1 fc2": (("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2"), {2: (9, 17)}),
     "stage 3 blocks 12-17: qkv proj fc1 fc2": (("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2"), {2: (12, 17)}),
+    "stage 3 blocks 2-17: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (2, 17)}),
+    "stage 3 blocks 3-17: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (3, 17)}),
+    "stage 3 blocks 4-17: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (4, 17)}),
+    "stage 3 blocks 5-17: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2"), {2: (5, 17)}),
+    "stage 3 blocks 6-17: qkv fc1 fc2 + stage 4: fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2", "fc1.s3", "fc2.s3"), {2: (6, 17)}),
+    "stage 3 blocks 6-17: qkv fc1 fc2 + stage 4: qkv fc1 fc2": (("qkv.s2", "fc1.s2", "fc2.s2", "qkv.s3", "fc1.s3", "fc2.s3"), {2: (6, 17)}),
+    "stage 3 blocks 6-17: qkv proj fc1 fc2": (("qkv.s2", "proj.s2", "fc1.s2", "fc2.s2"), {2: (6, 17)}),
+    "stage 3 blocks 4-17: fc1 fc2": (("fc1.s2", "fc2.s2"), {2: (4, 17)}),
 }
 
 
@@ -411,9 +420,10 @@ def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, 
     switched with mnx_set_op_terms (same weights, same kernels): features vs the reference, raw logits of steps 0..3 and
     teacher-forced log-prob error + argmax flips along the reference ids — on the four cases of the molecule-like fixture (6 and
     32 rows, trained-like and plain decoder: 6855 steps) and on the hostile checkpoint (16 rows, 6008 steps). Recorded for every
-    table (profiles/r06_two_term_tables_gpu.json is this test's report); asserted for the SHIPPED table: 0 flips, log-probs within
-    5e-4 and raw logits within 6e-4 everywhere (measured 1.8e-4 / 4.96e-4; north_star: 1e-3) — and for every table 0 flips (the
-    record shows what each costs: no table of useful size leaves the raw logits under 5e-4 with margin, so the mode is opt-in).
+    table (profiles/r06_two_term_tables_gpu.json is this test's report); asserted for the SHIPPED table — the default mode —: 0
+    flips, log-probs and raw logits within 5e-4 everywhere (measured 1.8e-4 / 4.997e-4; north_star: 1e-3) — and for every table 0
+    flips. The record shows what each costs; the maximum over 29 000 raw logits is a noisy statistic (block ranges of stage 3:
+    2.4e-4 .. 4.7e-4 with no order in it), the feature rms error (1.0e-4 .. 1.5e-4) is the smooth one.
     The CPU emulation of the same tables: profiles/r06_two_term_study*.json."""
     from molnextr_amd.engine import Engine, FP16X3M_BLOCKS, FP16X3M_TWO_TERM
     dev = torch.device("cuda:0")
@@ -471,4 +481,4 @@ def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, 
     for name, r in rec.items():
         assert r["flips"] == 0, (name, r)
         if name.startswith("fp16x3m"):
-            assert r["logp_max_err"] < 5e-4 and r["logit_max_err"] < 6e-4, (name, r["logp_max_err"], r["logit_max_err"])
+            assert r["logp_max_err"] < 5e-4 and r["logit_max_err"] < 5e-4, (name, r["logp_max_err"], r["logit_max_err"])
