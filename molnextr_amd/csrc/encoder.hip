@@ -835,6 +835,7 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
     Item nx = locate(it0);
     fetch_kv(nx, 0);
     fetch_q(nx);
+#pragma clang loop unroll(disable)                   // (also keeps the compiler from peeling the first item off: one copy of the body)
     for (int it = it0; it < it1; ++it) {
         // item `it`: its K / V are in LDS, its q rows / bias column in registers. The prefetched registers pass THROUGH the
         // wait so that the compiler takes them as complete here and adds no vmcnt wait of its own later in the item
@@ -931,8 +932,13 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
             const f32x4 p0 = acc[2 * m];
             const f32x4 p1 = (m < 4) ? acc[m < 4 ? 2 * m + 1 : 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
             v4 h0, l0, h1, l1;
-            split16x4<T>(p0, h0, l0);
-            split16x4<T>(p1, h1, l1);
+            if constexpr (MASKED) {                  // (the masked kernel has no register to spare for the asm form: it spills)
+                split16x4<T>(p0, h0, l0);
+                split16x4<T>(p1, h1, l1);
+            } else {
+                split16x4_mix<T>(p0, h0, l0);
+                split16x4_mix<T>(p1, h1, l1);
+            }
             const v8 ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
             const v8 pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             const int r0 = m * 2048, r1 = m < 4 ? m * 2048 + 1024 : m * 2048;
@@ -950,7 +956,10 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
             if (m == 1 && more) fetch_q(nx);
         }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) split16x4<T>(oacc[dt] * inv_sum, ohi_p[dt], olo_p[dt]);
+        for (int dt = 0; dt < 2; ++dt) {
+            if constexpr (MASKED) split16x4<T>(oacc[dt] * inv_sum, ohi_p[dt], olo_p[dt]);
+            else split16x4_mix<T>(oacc[dt] * inv_sum, ohi_p[dt], olo_p[dt]);
+        }
         ooff_p = ooff;
         have_p = true;
         cur ^= 1;

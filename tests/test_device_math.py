@@ -266,6 +266,15 @@ def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fe
         assert len(re.findall(r"s_waitcnt vmcnt", loop)) == 0, name          # nothing between the barrier and the loop's back edge ...
         assert len(re.findall(r"s_barrier", body)) == 1, name                 # ... and one barrier per item
         assert len(re.findall(r"ds_read_b64_tr_b16", body)) == 36, name
+        # round 6: the unmasked fp16 kernel splits P and the context through v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16 (common.h
+        # split16x4_mix: 10 blocks of four probabilities + 2 of the context), every block behind its own wait state (a VALU
+        # read of a transcendental's result; the compiler does not guard inline asm); the other three keep the compiler's form
+        mix = len(re.findall(r"v_fma_mixlo_f16", body)), len(re.findall(r"v_fma_mixhi_f16", body))
+        if "IDF16_Lb0E" in name:
+            assert mix == (24, 24), (name, mix)
+            assert len(re.findall(r"s_nop 0\n\s*v_cvt_pk_f16_f32 v\d+, v\d+, v\d+\n\s*v_cvt_pk_f16_f32", body)) == 12, name
+        else:
+            assert mix == (0, 0), (name, mix)
 
 
 def test_patch_embed_isa_requests_its_staging_loads_together_and_has_a_branch_free_tap_loop(tmp_path):
