@@ -78,8 +78,10 @@ __device__ __forceinline__ void split16x4(f32x4 v, typename H16<T>::v4& hi, type
 // look for that in front of inline asm (it does put the wait state between this block's partial writes and their consumer).
 // The packed fp32 forms of the neighbouring arithmetic (v_pk_fma_f32 for the scores, v_pk_add_f32 for the exponent arguments)
 // were measured in the same pass and are NOT used: compiler-generated, 72 instructions fewer, and a few thousand to 10^5 of
-// 7.5e7 output words WRONG, different ones each run (profiles/r06_attn_lab_diet.txt) — a forwarding hazard into v_max3 / v_exp
-// that neither the hardware interlock nor this compiler covers.
+// 7.5e7 output words WRONG, different ones each run (profiles/r06_attn_lab_diet.txt). The cause was not isolated: the pattern
+// on its own — v_pk_add_f32 straight into v_exp_f32, nine-wave workgroups, with and without an MFMA stream — forwards
+// correctly (tools/probes/pk_f32_forward.hip: 0 of 9.7e9 results differ), and the kernel without them is word-identical to
+// the per-item kernel at every stage.
 template <typename T>
 __device__ __forceinline__ void split16x4_mix(f32x4 v, typename H16<T>::v4& hi, typename H16<T>::v4& lo) { split16x4<T>(v, hi, lo); }
 template <>
