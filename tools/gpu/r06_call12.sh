@@ -1,5 +1,7 @@
 #!/bin/bash
-# which piece of the window attention's instruction diet breaks the word compare (tools/attn_lab variants)
+# which piece of the window attention's instruction diet breaks the word compare: tools/attn_lab built with -DMNX_ATTN_MIX=<m>
+# -DMNX_ATTN_PK=<p> into lab_m<m>_p<p> (record of the call; the two switches and the packed-fp32 paths they selected were removed from
+# encoder.hip after this measurement, profiles/r06_attn_lab_diet.txt has the output)
 cd /root/repo
 mkdir -p gpurun_out
 for v in m0_p0 m1_p0 m0_p1 m0_p2 m1_p3 m0_p0 m1_p0 m0_p1 m0_p2 m1_p3; do

@@ -217,8 +217,10 @@ def forced_decode(features, sd, ids, lens, cfg=DECODER_DEFAULT, kv=None):
     B, S_, D = memory.shape
     h, dh, L = cfg.heads, cfg.d_model // cfg.heads, cfg.layers
     mem_kv = OD.cross_kv(memory, sd, cfg)
+    if kv is not None and not isinstance(kv, tuple):
+        kv = (kv, kv)       # (rounding of keys, rounding of values)
     if kv is not None:      # [B, h, S, dh] per layer: rounded per head
-        mem_kv = [tuple(torch.stack([kv(t[:, hh]) for hh in range(h)], 1) for t in pair) for pair in mem_kv]
+        mem_kv = [tuple(torch.stack([kv[i](t[:, hh]) for hh in range(h)], 1) for i, t in enumerate(pair)) for pair in mem_kv]
     emb_w = sd[P + "embeddings.make_embedding.emb_luts.0.weight"]
     pe = sd[P + "embeddings.make_embedding.pe.pe"].reshape(-1, D)
     T = int(lens.max())
@@ -239,8 +241,8 @@ def forced_decode(features, sd, ids, lens, cfg=DECODER_DEFAULT, kv=None):
             k_new = OD._lin(xn, sd, lp + ".self_attn.linear_keys").reshape(n, h, dh)
             v_new = OD._lin(xn, sd, lp + ".self_attn.linear_values").reshape(n, h, dh)
             if kv is not None:
-                k_new = torch.stack([kv(k_new[:, hh]) for hh in range(h)], 1)
-                v_new = torch.stack([kv(v_new[:, hh]) for hh in range(h)], 1)
+                k_new = torch.stack([kv[0](k_new[:, hh]) for hh in range(h)], 1)
+                v_new = torch.stack([kv[1](v_new[:, hh]) for hh in range(h)], 1)
             self_k[l, idx, :, step] = k_new
             self_v[l, idx, :, step] = v_new
             q = OD._lin(xn, sd, lp + ".self_attn.linear_query")
@@ -280,7 +282,7 @@ def main():
                                                 "synthetic_checkpoint(1, stress=True) against tests/golden/pixels_stress")
     ap.add_argument("--ranges", action="store_true", help="print max |operand| per op class (fp16 range check)")
     ap.add_argument("--kv", default=None,
-                    help="K / V cache byte study instead of the operand schemes: comma list of bf16,fp16,bf16+8,fp16+8,int16b,int20b,int24b — the decoder "
+                    help="K / V cache byte study instead of the operand schemes: comma list of bf16,fp16,bf16+8,fp16+8,int12b,int16b,int20b,int24b or <keys>/<values> pairs of them (int24b/int16b) — the decoder "
                          "runs teacher-forced on the fp32 features with every cached key / value rounded to that format")
     ap.add_argument("--two", action="append", default=[],
                     help="repeatable: comma list of op classes that run on TWO terms (ah.wh + ah.wl: the activation's lo plane is "
@@ -319,10 +321,18 @@ def main():
         fmt = {"bf16": (8, False, 2), "fp16": (11, True, 2), "bf16+8": (16, False, 3), "fp16+8": (19, True, 3), "fp32": (24, False, 4)}
         for b_ in (12, 16, 20, 24):      # block fixed point: int<b> per element + one exponent byte per 32-channel row
             fmt[f"int{b_}b"] = (b_, None, b_ / 8 + 1 / 32)
+        def rounding(fname):
+            b, rg, _ = fmt[fname]
+            return (lambda t: round_block(t, b)) if rg is None else (lambda t: round_sig(t, b, rg))
         for name in args.kv.split(","):
-            bits, rng, nbytes = fmt[name]
             t0 = time.time()
-            rnd = (lambda t: round_block(t, bits)) if rng is None else (lambda t: round_sig(t, bits, rng))
+            if "/" in name:           # "<keys>/<values>": different formats for the two halves of the cache
+                kn, vn = name.split("/")
+                rnd = (rounding(kn), rounding(vn))
+                bits, nbytes = min(fmt[kn][0], fmt[vn][0]), (fmt[kn][2] + fmt[vn][2]) / 2
+            else:
+                bits, _, nbytes = fmt[name]
+                rnd = rounding(name)
             lp, fl = forced_decode(ref, ck["decoder"], ids, lens, kv=rnd)
             fm = [float(margin[b, t]) for b, t in zip(*np.nonzero(fl & m))]
             rec = {"kv_format": name, "bytes_per_element": nbytes, "significant_bits": bits, "images": N,
