@@ -81,6 +81,32 @@ def test_degree16_polynomial_gelu_is_as_accurate_as_the_reference_formula():
     assert np.sqrt((err ** 2).mean()) < 3.0e-8
 
 
+def test_fma_mix_split_is_the_two_rounding_split():
+    """common.h split16x4_mix derives the lo plane as ONE rounding of fma(hi, -1, v) to fp16 (v_fma_mix{lo,hi}_f16) where
+    split16x4 rounds twice: t = fl32(v - hi), lo = RN16(t). They agree bit for bit iff v - hi is exactly representable in fp32
+    for every fp32 v and hi = RN16(v) — checked here on 4M values covering the normal range, the fp16 subnormal range (where hi
+    is a multiple of 2^-24), the overflow edge and the probabilities x 2^10 the window attention actually splits (the GPU check
+    of the same statement is tools/attn_lab's word compare: profiles/r06_attn_lab_diet.txt)."""
+    rng = np.random.default_rng(5)
+    v = np.concatenate([
+        rng.standard_normal(1 << 20).astype(np.float32) * np.float32(3.0),
+        (rng.random(1 << 20).astype(np.float32) * np.float32(1024.0)),                                   # P x 2^10
+        np.exp2(rng.uniform(-30, -10, 1 << 20)).astype(np.float32) * rng.choice(np.float32([-1, 1]), 1 << 20),   # subnormal hi / lo
+        np.exp2(rng.uniform(10, 15.99, 1 << 20)).astype(np.float32),                                     # up to the fp16 maximum
+    ])
+    hi = v.astype(np.float16)
+    ok = np.isfinite(hi.astype(np.float32))
+    d64 = v.astype(np.float64) - hi.astype(np.float64)                 # exact
+    d32 = v - hi.astype(np.float32)                                     # what __fsub_rn gives
+    assert np.array_equal(d64[ok], d32[ok].astype(np.float64)), "v - RN16(v) must be exact in fp32"
+    lo_two = d32.astype(np.float16)                                     # split16x4: second rounding of the fp32 difference
+    lo_one = d64.astype(np.float16)                                     # split16x4_mix: one rounding of the exact fma
+    assert np.array_equal(lo_two[ok].view(np.uint16), lo_one[ok].view(np.uint16))
+    # and the pair carries v to 2^-22 |v| (or 2^-25 absolute in the subnormal range)
+    err = np.abs(hi[ok].astype(np.float64) + lo_one[ok].astype(np.float64) - v[ok].astype(np.float64))
+    assert np.all(err <= np.maximum(np.abs(v[ok]).astype(np.float64) * 2.0 ** -22, 2.0 ** -25))
+
+
 def test_gemm256_vmcnt_bookkeeping_constants():
     """The counted waits of gemm256.hip are derived from how many vector-memory operations a wave issues per tile;
     the constants the derivation uses must match the code that issues them."""
