@@ -749,8 +749,20 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
     for (int i = threadIdx.x; i < 4 * WN; i += 576) {
         const int var = i / WN, t = i % WN, ty = t / WS, tx = t % WS;
         const int reg = ((var & 2) ? (ty < WS - shift ? 1 : 2) : 0) * 3 + ((var & 1) ? (tx < WS - shift ? 1 : 2) : 0);
-        kinfo4[i] = (ty * (2 * WS - 1) + tx) | (reg << 16);
+        int e = (ty * (2 * WS - 1) + tx) | (reg << 16);
+        if (!MASKED && var == 1) e = (ty * W + tx) * 6 * C;      // the unmasked kernel's offset tables, see below
+        if (!MASKED && var == 2) e = (ty * W + tx) * 2 * C;
+        kinfo4[i] = e;
     }
+    // Unmasked kernel (round 6): its windows never wrap around the image (cls 0: no shift; cls 1: the inner windows of a shifted
+    // layer), so the row of window token t is a per-window base (scalar arithmetic) + ty * W + tx, and every byte offset a lane
+    // needs is "scalar base + table[t]": two 144-entry tables — (ty W + tx) 6C, the token's offset in a qkv plane, and
+    // (ty W + tx) 2C, in a context plane — in the slots of mask variants 1 and 2, which this instantiation never reads. One LDS
+    // read replaces ~30 VALU operations (three of them quarter-rate integer multiplies) per offset, three offsets per item. The
+    // tables are complete at the first barrier: the fetches in front of the loop take the arithmetic path.
+    // (written by the loop above: every entry of kinfo4 has ONE writer)
+    const int* rel_qkv = kinfo4 + WN;
+    const int* rel_ctx = kinfo4 + 2 * WN;
     // Register diet: the loop body needs <= 80 VGPRs for two workgroups per CU (a 9-wave workgroup puts 3 waves on
     // SIMD 0, two of them 6: 512 / 6). Everything derived from the lane id (fragment coordinates, window coordinates of
     // the rows a lane fetches, LDS addresses) is therefore RE-derived at each use from an opaque copy of threadIdx.x —
@@ -797,11 +809,22 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
         int x = w.wx * WS + tx + shift; if (x >= W) x -= W;
         return (unsigned)((w.b * H + y) * W + x);
     };
+    // byte offset of (token `key`, head of the item) in a qkv plane / in a context plane (< 2^32)
+    auto qkv_off = [=](const Item& w, int key, bool tab) {
+        if (!MASKED && tab)
+            return (unsigned)(((w.b * H + w.wy * WS + shift) * W + w.wx * WS + shift) * 6 * C + w.head * HD * 2) + (unsigned)rel_qkv[key];
+        return (token_row(w, key) * 3u * (unsigned)C + (unsigned)(w.head * HD)) * 2u;
+    };
+    auto ctx_off = [=](const Item& w, int key, bool tab) {
+        if (!MASKED && tab)
+            return (unsigned)(((w.b * H + w.wy * WS + shift) * W + w.wx * WS + shift) * 2 * C + w.head * HD * 2) + (unsigned)rel_ctx[key];
+        return (token_row(w, key) * (unsigned)C + (unsigned)(w.head * HD)) * 2u;
+    };
     // DMA: wave w moves key rows 16w..16w+15, lane l row 16w + l/4, LDS piece l%4 (K: global piece l%4; V: global
     // piece (l%4) ^ ((l >> 4) & 3), see above)
-    auto fetch_kv = [&](const Item& w, int buf) {
+    auto fetch_kv = [&](const Item& w, int buf, bool tab) {
         const int lane = thread_id() & 63;
-        const unsigned kb = (token_row(w, wave * 16 + (lane >> 2)) * 3u * (unsigned)C + (unsigned)(w.head * HD)) * 2u;   // bytes, < 2^32
+        const unsigned kb = qkv_off(w, wave * 16 + (lane >> 2), tab);
         const unsigned offK = kb + (unsigned)C * 2u + (unsigned)(lane & 3) * 16u;
         const unsigned offV = kb + (unsigned)C * 4u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * WA_BUF + wave * 1024));
@@ -817,15 +840,14 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
     float tab_n;
     int var_n;
     unsigned ooff_n;                                // bytes into a context plane; < 2^32 (M*C*2 <= 5.3e8)
-    auto fetch_q = [&](const Item& w) {             // MFMA role: query 16w + fr, channel group fg
+    auto fetch_q = [&](const Item& w, bool tab) {   // MFMA role: query 16w + fr, channel group fg
         const int tid = thread_id(), fr = tid & 15, fg = (tid >> 4) & 3;
-        const unsigned qrow = token_row(w, wave * 16 + fr);
-        const unsigned qb = (qrow * 3u * (unsigned)C + (unsigned)(w.head * HD + fg * 8)) * 2u;
+        const unsigned qb = qkv_off(w, wave * 16 + fr, tab) + (unsigned)(fg * 16);
         qh_n = *(const v8*)(plane0 + qb);
         ql_n = *(const v8*)(plane1 + qb);
         tab_n = tid < 529 ? *(const float*)((const char*)table + (unsigned)(tid * heads + w.head) * 4u) : 0.f;
         var_n = MASKED ? (w.wy == nWh - 1 ? 2 : 0) + (w.wx == nWw - 1 ? 1 : 0) : 0;
-        ooff_n = (qrow * (unsigned)C + (unsigned)(w.head * HD + fg * 4)) * 2u;
+        ooff_n = ctx_off(w, wave * 16 + fr, tab) + (unsigned)(fg * 8);
     };
 
     v4 ohi_p[2], olo_p[2];
@@ -833,8 +855,8 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
     bool have_p = false;
     int cur = 0;
     Item nx = locate(it0);
-    fetch_kv(nx, 0);
-    fetch_q(nx);
+    fetch_kv(nx, 0, false);
+    fetch_q(nx, false);
 #pragma clang loop unroll(disable)                   // (also keeps the compiler from peeling the first item off: one copy of the body)
     for (int it = it0; it < it1; ++it) {
         // item `it`: its K / V are in LDS, its q rows / bias column in registers. The prefetched registers pass THROUGH the
@@ -851,7 +873,7 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
         const bool more = it + 1 < it1;
         if (more) {
             nx = locate(it + 1);
-            fetch_kv(nx, cur ^ 1);
+            fetch_kv(nx, cur ^ 1, true);
         }
         if (have_p) {
 #pragma unroll
@@ -953,7 +975,7 @@ __global__ __launch_bounds__(576, 6) void window_attn_pipe_kernel(const T* __res
             }
             // the next item's q rows / bias column: issued here, not with the DMA, because only now (the first 64 keys'
             // probabilities are consumed) are there registers for them; the rest of the item covers the latency
-            if (m == 1 && more) fetch_q(nx);
+            if (m == 1 && more) fetch_q(nx, true);
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {

@@ -296,6 +296,11 @@ def test_window_attn_pipe_isa_fits_two_workgroups_per_cu_and_never_drains_the_fe
         # split16x4_mix: 10 blocks of four probabilities + 2 of the context), every block behind its own wait state (a VALU
         # read of a transcendental's result; the compiler does not guard inline asm); the other three keep the compiler's form
         mix = len(re.findall(r"v_fma_mixlo_f16", body)), len(re.findall(r"v_fma_mixhi_f16", body))
+        # ... and the unmasked kernels take their byte offsets from LDS tables: 4 integer multiplies left in the whole item
+        # (the masked ones, whose windows wrap around the image, re-derive them: 16)
+        loop_body = body[body.index("Inner Loop Header"):]
+        n_mul = len(re.findall(r"v_mul_lo_u32|v_mul_hi_u32|v_mad_u64_u32", loop_body))
+        assert n_mul <= (6 if "Lb0E" in name else 20), (name, n_mul)
         if "IDF16_Lb0E" in name:
             assert mix == (24, 24), (name, mix)
             assert len(re.findall(r"s_nop 0\n\s*v_cvt_pk_f16_f32 v\d+, v\d+, v\d+\n\s*v_cvt_pk_f16_f32", body)) == 12, name
