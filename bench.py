@@ -9,9 +9,9 @@
 and the node has that many GPUs — it never prints an `n_gpus` it did not use.
 
 One "step" = one pass of the whole hot path over one batch of 32 synthetic 384x384x3 images per GPU, inputs already
-resident in HBM: Swin-B encode (MFMA GEMMs; default operand mode fp16x3m = split fp16 operands, three 16-bit MFMA terms
-per product — two in qkv / fc1 / fc2 of Swin stage 3 —, fp32 accumulate: the fastest mode whose tokens / atoms / bonds equal
-the reference's from pixels with logits within 5e-4) ->
+resident in HBM: Swin-B encode (MFMA GEMMs; default operand mode fp16x3 = split fp16 operands, three 16-bit MFMA terms
+per product, fp32 accumulate: the fastest mode whose tokens / atoms / bonds equal the reference's from pixels with the
+logits a factor of five inside north_star's 1e-3) ->
 enc_transform + cross-KV -> greedy decode until EOS / 480 tokens
 (reference default max_length) -> on-device atom positions -> bond head; with N > 1 the batch of N*32 images is sharded
 by image across the ranks and the fixed-size result records are all-gathered with RCCL inside the timed region.
@@ -33,8 +33,8 @@ Rank 0 prints ONE JSON line (contract in the task statement). Beyond the contrac
                   two per-row decode attention kernels (isolated probe at a fixed operating point): algorithmic bytes /
                   duration against 8 TB/s
   sub_results     (N = 1 only, after the timed region) latency mode (one batch of 32 at a time), fixed-T=128 decode
-                  (deterministic work), beam 5 x batch 32, the throughput of the three-term mode fp16x3 and of the plain bf16
-                  operand mode (fastest, not token-exact) next to the default mode's
+                  (deterministic work), beam 5 x batch 32, the throughput of the opt-in two-term mode fp16x3m and of the plain
+                  bf16 operand mode (fastest, not token-exact) next to the default mode's
   cpu_baseline    the CPU oracle (oracle/, bit-equal to the reference in the build container) on a bounded sample of
                   the same workload on this box's host cores: thread sweep, B in {1, 32}, encoder /
                   decoder split, natural and fixed-T=128 decode, median of 3 after a warm-up, 1-thread figure, lscpu model
@@ -390,12 +390,12 @@ def main():
     ap.add_argument("--beam", type=int, default=1, help="beam size; > 1 times BASELINE config 5 through mnx_predict_beam")
     ap.add_argument("--max-len", type=int, default=480)
     ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["fp16x3", "fp16x3m", "bf16x3", "bf16", "fp16", "fp32"],
-                    help="encoder operand mode. fp16x3m (default since round 6): split fp16 operands, three MFMA terms per product except "
-                         "in the Linear layers of molnextr_amd.engine.FP16X3M_TWO_TERM (qkv / fc1 / fc2 of Swin stage 3), which run on two "
-                         "(activation lo plane dropped): every token / atom / bond equal to the reference's on both fixture checkpoints, "
-                         "log-probs within 1.8e-4, raw logits within 5.0e-4 (north_star: 1e-3; the round-5 review's gate for a default "
-                         "mode: <= 5e-4) — tests/test_gpu_pixels.py, profiles/r06_two_term_tables_gpu.json; fp16x3: three terms "
-                         "everywhere, fp32-class features (5e-6), logits within 1e-4")
+                    help="encoder operand mode. fp16x3 (default): three MFMA terms per product everywhere, fp32-class features (6e-6), "
+                         "raw logits within 2e-4 of the reference's at every step; fp16x3m (opt-in): the same with the Linear layers of "
+                         "molnextr_amd.engine.FP16X3M_TWO_TERM (qkv / fc1 / fc2 of Swin stage 3) on two terms (activation lo plane "
+                         "dropped): every token / atom / bond still the reference's on everything measured (0 flips in 90 000 "
+                         "teacher-forced steps), raw logits within 5.0e-4 on the fixtures and 8.7e-4 on 384 further images (north_star: "
+                         "1e-3) — tests/test_gpu_pixels.py, profiles/r06_two_term_tables_gpu.json, r06_extended_parity_*.json")
     ap.add_argument("--encode-batch", type=int, default=int(os.environ.get("MNX_ENCODE_BATCH", "512")),
                     help="images per encoder launch group (a multiple of 32; decode batches stay 32). 512 = 16 reference "
                          "batches: every Linear of Swin stage 3 then has a WHOLE number of rounds of 256 output tiles of 256x256 "
@@ -637,10 +637,11 @@ def main():
                 eng.set_op_terms(None)
                 two_what = (f"the Linear layers {', '.join(FP16X3M_TWO_TERM)} (qkv / fc1 / fc2 of Swin stage 3, 60 % of the encoder's GEMM "
                             "time) on TWO MFMA terms — the activation's lo plane dropped —, "
-                            f"{round(gemm_mfma_terms(True, two_term_layers(FP16X3M_TWO_TERM)), 3)} terms per product on average: every "
-                            "token / atom / bond equals the reference's on both fixture checkpoints (0 flips in 12863 teacher-forced "
-                            "steps), log-probs within 1.8e-4, raw logits within 5.0e-4 of the reference's "
-                            "(tests/test_gpu_pixels.py, profiles/r06_two_term_tables_gpu.json)")
+                            f"{round(gemm_mfma_terms(True, two_term_layers(FP16X3M_TWO_TERM)), 3)} terms per product on average. Opt-in: every "
+                            "token / atom / bond equals the reference's on everything measured (0 flips in 12863 teacher-forced steps "
+                            "of the fixtures + 77790 of 384 further images), log-probs within 3.7e-4; raw logits within 5.0e-4 on the "
+                            "fixtures but up to 8.7e-4 on the further images — inside north_star's 1e-3 without the headroom a default "
+                            "needs (tests/test_gpu_pixels.py, profiles/r06_two_term_tables_gpu.json, r06_extended_parity_*.json)")
                 sub["throughput_mode_" + other] = {
                     "what": (f"the same {ns} steps with compute_dtype FP16X3 on the same engine: THREE MFMA terms in every layer (features within "
                              "6e-6, raw logits within 8e-5 of the reference's); this line's own mode is FP16X3M = " + two_what
@@ -687,10 +688,10 @@ def main():
             "roofline": roofline, "roofline_extra": extra, "sub_results": sub, "cpu_baseline": cpu,
             "library_sha16": library_sha16(),
             "parity_note": ("SMILES exact-match vs the reference is checked on the raw token SMILES + atom / bond sets (RDKit is not "
-                            "installable here). dtype fp16x3m (the default), fp16x3 and fp32: logits within 1e-3, every token / atom / "
-                            "bond equal to the reference from pixels (tests/test_gpu_pixels.py, 32 + 6 images, free-running and "
-                            "teacher-forced); fp16x3m: log-probs within 5e-4 and raw logits within 5e-4 "
-                            "asserted (1.8e-4 / 5.0e-4 measured), fp16x3 2e-5 / 8e-5; bf16x3: logits within 1e-3, flips only on near-ties; plain bf16 / fp16: argmax near-ties "
+                            "installable here). dtype fp16x3 (this line's default) and fp32: logits within 1e-3 (measured 2e-4 over every "
+                            "step), every token / atom / bond equal to the reference from pixels (tests/test_gpu_pixels.py, 32 + 6 images, "
+                            "free-running and teacher-forced; tools/extended_parity.py on further images); fp16x3m (opt-in): the same "
+                            "exactness, raw logits within 5e-4 on the fixtures (asserted) and 8.7e-4 on 384 further images; bf16x3: logits within 1e-3, flips only on near-ties; plain bf16 / fp16: argmax near-ties "
                             "flip (profiles/r04_pixels_parity.json, DESIGN.md §6.1, §6.R3); the exact modes also pass on a second, hostile "
                             "checkpoint (tests/golden/pixels_stress.*)"),
         }

@@ -26,16 +26,17 @@ SYMBOLS = ("mnx_abi_version", "mnx_create", "mnx_destroy", "mnx_last_error", "mn
            "mnx_gemm16_split", "mnx_decode_forced", "mnx_gemm_clock", "mnx_probe_mfma", "mnx_set_op_terms")
 
 # Encoder operand modes (include/molnextr_hip.h MNX_DTYPE_*). "fp16x3" — split fp16 operands, three MFMA terms per
-# product, fp32-class results (features within 6e-6, raw logits within 8e-5 of the reference's).
-# "fp16x3m" — the DEFAULT since round 6 — is fp16x3 with the layers of FP16X3M_TWO_TERM (qkv, fc1, fc2 of Swin stage 3: 60 % of the
-# encoder's GEMM time) on TWO terms: the activation's lo plane dropped, the weight's kept. Measured on both fixture checkpoints
-# (12863 teacher-forced steps, 54 molecules free-running): every token / atom / bond the reference's, 0 argmax flips, log-probs
-# within 1.8e-4, raw logits within 5.0e-4 of the reference's — north_star allows 1e-3, the round-5 review's gate for making it
-# the default was <= 5e-4 (profiles/r06_two_term_tables_gpu.json: every table that was measured, block ranges included;
-# tests/test_gpu_pixels.py asserts the gate). dtype="fp16x3" buys back the last decimal of the log-probs for 8-11 % of the
-# throughput; both run the same weights and kernels (Engine.set_op_terms switches between them on a live engine).
+# product, fp32-class results — is the default: it is the fastest mode whose results stay a factor of five inside north_star's
+# tolerance (raw logits within 2.0e-4 of the reference's over EVERY step of 8 000 - 46 000-step checks, features within 7e-6).
+# "fp16x3m" (opt-in) is fp16x3 with the layers of FP16X3M_TWO_TERM (qkv, fc1, fc2 of Swin stage 3: 60 % of the encoder's GEMM time)
+# on TWO terms — the activation's lo plane dropped, the weight's kept: +8-11 % throughput. On the committed fixtures (12863
+# teacher-forced steps, both checkpoints) every token / atom / bond is the reference's, log-probs within 1.8e-4, raw logits of
+# steps 0..3 within 4.997e-4 — the round-5 review's 5e-4 gate met to the letter; on 384 further images against the oracle
+# (tools/extended_parity.py, 77 790 steps, still 0 flips, every row exact) the raw logits reach 7.2e-4 / 8.7e-4 (hostile
+# checkpoint): inside north_star's 1e-3, but without the headroom a default needs (profiles/r06_extended_parity_*.json,
+# r06_two_term_tables_gpu.json; tests/test_gpu_pixels.py). Both modes run the same weights and kernels (Engine.set_op_terms).
 DTYPES = {"bf16": 0, "fp16": 1, "fp32": 2, "bf16x3": 3, "fp16x3": 4, "fp16x3m": 5}
-DEFAULT_DTYPE = "fp16x3m"
+DEFAULT_DTYPE = "fp16x3"
 SPLIT_CLASSES = {"qkv": 1, "attn": 2, "proj": 4, "fc1": 8, "fc2": 16, "merge": 32}
 FP16X3M_BLOCKS = {}                                       # {stage: (first_block, last_block)}: MNX_FP16X3M_FIRST_BLOCK_BY_STAGE
 FP16X3M_TWO_TERM = ("qkv.s2", "fc1.s2", "fc2.s2")       # include/molnextr_hip.h MNX_FP16X3M_TWO_TERM_BY_STAGE (tags: "cls" or "cls.sN", N 0-based)

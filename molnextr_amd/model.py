@@ -132,11 +132,12 @@ class molnextr:
     the literal 'synthetic' opts into the deterministic hash-generated checkpoint (tests / bench only: its predictions
     are meaningless as chemistry). There is no default: like the reference, the model cannot run without weights.
     device: torch.device('cuda', i) — an MI355X is required.
-    dtype: encoder operand mode. 'fp16x3m' (the default, engine.DEFAULT_DTYPE: split fp16 operands, three MFMA terms per product
-    except in the Linear layers of engine.FP16X3M_TWO_TERM, which run on two: log-probs within 1.8e-4, raw logits within 5e-4 of
-    the reference's, every token / atom / bond the reference's on both fixture checkpoints), 'fp16x3' (three terms everywhere:
-    features equal the reference's to fp32 rounding level, 8-11 % slower), 'bf16x3' (three terms with the fp32 exponent
-    range), 'fp32' (exact-fp32 MFMA, slowest), 'bf16' / 'fp16' (fastest; argmax decisions near a tie can differ)."""
+    dtype: encoder operand mode. 'fp16x3' (the default, engine.DEFAULT_DTYPE: split fp16 operands, three MFMA terms per product:
+    features equal the reference's to fp32 rounding level, logits within 2e-4), 'fp16x3m' (opt-in: the Linear layers of
+    engine.FP16X3M_TWO_TERM on two terms, +8-11 % throughput; every token / atom / bond still the reference's on everything
+    measured, raw logits within 5e-4 on the fixtures and 8.7e-4 on further images — inside north_star's 1e-3 without headroom),
+    'bf16x3' (three terms with the fp32 exponent range), 'fp32' (exact-fp32 MFMA, slowest), 'bf16' / 'fp16' (fastest; argmax
+    decisions near a tie can differ)."""
 
     def __init__(self, model_path, device=None, max_batch: int = 32, dtype: str = DEFAULT_DTYPE,
                  device_preprocess: bool = True):

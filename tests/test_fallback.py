@@ -12,7 +12,7 @@ from molnextr_amd.engine import DEFAULT_DTYPE, MNX_ERR_RANGE, MnxError, range_fa
 def test_fallback_decision():
     rng = MnxError("mnx_predict failed (-6): non-finite features", code=MNX_ERR_RANGE)
     assert range_fallback_dtype(rng, "fp16x3") == "bf16x3"
-    assert DEFAULT_DTYPE == "fp16x3m" and range_fallback_dtype(rng, DEFAULT_DTYPE) == "bf16x3"
+    assert DEFAULT_DTYPE == "fp16x3" and range_fallback_dtype(rng, "fp16x3m") == "bf16x3"
     assert range_fallback_dtype(rng, "fp16") == "bf16"
     assert range_fallback_dtype(rng, "bf16x3") is None and range_fallback_dtype(rng, "fp32") is None
     assert range_fallback_dtype(MnxError("capacity", code=-5), "fp16x3") is None

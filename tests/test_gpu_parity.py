@@ -927,7 +927,7 @@ def test_reference_format_checkpoint_loads_through_public_api(dev, tmp_path):
 
 def test_facade_falls_back_to_the_bf16_split_mode_when_fp16_overflows(dev, tmp_path):
     """A checkpoint the reference runs without complaint but whose MLP hidden state leaves the fp16 range (fc1 of one block
-    x 3e5, its fc2 x 1 / 3e5: activations ~1e6): an fp16x3 engine (and the default fp16x3m one) reports MNX_ERR_RANGE; the facade must warn,
+    x 3e5, its fc2 x 1 / 3e5: activations ~1e6): the default fp16x3 engine (and an fp16x3m one) reports MNX_ERR_RANGE; the facade must warn,
     rebuild in bf16x3 (fp32 exponent range) and return what the fp32 oracle returns — not raise. A later call on a sane
     input must not inherit the flag (it is per call)."""
     from molnextr_amd.engine import DEFAULT_DTYPE, Engine, MnxError, MNX_ERR_RANGE
@@ -953,7 +953,7 @@ def test_facade_falls_back_to_the_bf16_split_mode_when_fp16_overflows(dev, tmp_p
         e.close()
     m = molnextr(src, dev, max_batch=4)
     try:
-        assert m.engine.dtype == DEFAULT_DTYPE == "fp16x3m"
+        assert m.engine.dtype == DEFAULT_DTYPE == "fp16x3"
         with pytest.warns(RuntimeWarning, match="bf16x3"):
             preds = m._with_fallback(lambda eng: predict_pipeline(eng, imgs.to(dev), m.tokenizer, ref_batch_size=3))
         assert m.engine.dtype == "bf16x3"

@@ -4,15 +4,17 @@
 
 Nothing of the GPU's output is handed to the checker. Per encoder operand mode:
 
-  * EXACT modes — `fp16x3` (split fp16 operands, three MFMA terms per product) and `fp32` (exact-fp32 MFMA): logits of steps 0..3 and the log-prob of every emitted token within 1e-3 (north_star's
+  * EXACT modes — `fp16x3` (split fp16 operands, three MFMA terms per product: the default of the facade and of bench.py)
+    and `fp32` (exact-fp32 MFMA): logits of steps 0..3 and the log-prob of every emitted token within 1e-3 (north_star's
     tolerance), every token id, length, atom position, coordinate and bond class EXACT for all 32 + 6 images,
     molecule-like and plain-random decoder, free-running AND teacher-forced;
-  * `fp16x3m` (fp16x3 with the Linears of engine.FP16X3M_TWO_TERM on TWO terms — the activation's lo plane dropped; the
-    DEFAULT of the engine, the facade and bench.py since round 6): the exact-mode assertions unchanged (0 flips over every
-    teacher-forced step, every free-running row and every molecule exact, both checkpoints), log-probs AND raw logits within
-    5e-4 — the round-5 review's gate for a default mode, half of north_star's 1e-3 (measured 1.8e-4 / 5.0e-4: the gate is met,
-    with no margin on the raw logits; the numbers are deterministic — the encoder is bit-reproducible and a one-tile decode
-    always takes the same tick form);
+  * `fp16x3m` (fp16x3 with the Linears of engine.FP16X3M_TWO_TERM on TWO terms — the activation's lo plane dropped; opt-in):
+    the exact-mode assertions unchanged (0 flips over every teacher-forced step, every free-running row and every molecule
+    exact, both checkpoints), log-probs AND raw logits within 5e-4 on these fixtures (measured 1.8e-4 / 4.997e-4: the round-5
+    review's gate for a default mode, met here to the letter — deterministic numbers: the encoder is bit-reproducible and a
+    one-tile decode always takes the same tick form). Why it is opt-in all the same: tools/extended_parity.py on 384 FURTHER
+    images against the oracle gives 7.2e-4 / 8.7e-4 raw-logit error (0 flips, every row exact) — inside north_star's 1e-3
+    without the headroom the gate was there to guarantee (profiles/r06_extended_parity_*.json);
   * `bf16x3` (split bf16 operands): the same logit gate (1e-3); token flips are allowed only where the teacher-forced
     trace proves a near-tie (below);
   * `fp16` / `bf16` (one 16-bit plane per operand, the fastest modes): measured, with gates at 2x the values committed in
@@ -42,7 +44,7 @@ CASES = [("m6", 6, 480, True), ("m32", 32, 480, True), ("p6", 6, 64, False), ("p
 EXACT_MODES = ("fp32", "fp16x3", "fp16x3m")
 # max |logit error| over steps 0..3 and max |log-prob error| along the reference trajectory; max |feature error| (features
 # have unit rms). Exact modes and bf16x3: north_star's 1e-3. 16-bit modes: 2x the measured values (profiles/r03_pixels_parity.json).
-# fp16x3m: raw logits and log-probs 5e-4 = the gate for a default mode (measured 4.997e-4 / 1.8e-4, profiles/r06_two_term_tables_gpu.json),
+# fp16x3m: raw logits and log-probs 5e-4 on these fixtures (measured 4.997e-4 / 1.8e-4, profiles/r06_two_term_tables_gpu.json),
 # features 2x the CPU emulation's 1.3e-3 max (profiles/r06_two_term_study*.json).
 LOGIT_TOL = {"fp32": 1e-3, "fp16x3": 1e-3, "fp16x3m": 5e-4, "bf16x3": 1e-3, "fp16": 2e-2, "bf16": 1.2e-1}
 LOGP_TOL = dict(LOGIT_TOL, fp16x3m=5e-4)
@@ -420,7 +422,7 @@ def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, 
     switched with mnx_set_op_terms (same weights, same kernels): features vs the reference, raw logits of steps 0..3 and
     teacher-forced log-prob error + argmax flips along the reference ids — on the four cases of the molecule-like fixture (6 and
     32 rows, trained-like and plain decoder: 6855 steps) and on the hostile checkpoint (16 rows, 6008 steps). Recorded for every
-    table (profiles/r06_two_term_tables_gpu.json is this test's report); asserted for the SHIPPED table — the default mode —: 0
+    table (profiles/r06_two_term_tables_gpu.json is this test's report); asserted for the SHIPPED table of the opt-in mode: 0
     flips, log-probs and raw logits within 5e-4 everywhere (measured 1.8e-4 / 4.997e-4; north_star: 1e-3) — and for every table 0
     flips. The record shows what each costs; the maximum over 29 000 raw logits is a noisy statistic (block ranges of stage 3:
     2.4e-4 .. 4.7e-4 with no order in it), the feature rms error (1.0e-4 .. 1.5e-4) is the smooth one.

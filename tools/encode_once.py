@@ -12,7 +12,7 @@ from molnextr_amd.engine import Engine  # noqa: E402
 
 ck = W.synthetic_checkpoint(0)
 B = int(os.environ.get("BATCH", "64"))
-eng = Engine(ck["encoder"], ck["decoder"], max_batch=B, dtype=os.environ.get("DTYPE", "fp16x3m"))
+eng = Engine(ck["encoder"], ck["decoder"], max_batch=B, dtype=os.environ.get("DTYPE", "fp16x3"))
 img = W.synthetic_images(4).cuda().repeat(B // 4, 1, 1, 1).contiguous()
 for _ in range(int(os.environ.get("ENCODES", "3"))):
     eng.encode(img)

@@ -13,13 +13,14 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 bash tools/gpu/profiles.sh
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_full20.log 2>&1; echo "bench20 rc=$?"; tail -1 gpurun_out/bench_full20.log | cut -c1-300
 timeout 600 python bench.py --no-cpu-baseline --no-sub > gpurun_out/bench_default.log 2>&1; echo "bench default rc=$?"; tail -1 gpurun_out/bench_default.log | cut -c1-200
-timeout 600 python bench.py --no-cpu-baseline --no-sub --dtype fp16x3 > gpurun_out/bench_default_fp16x3.log 2>&1; echo "bench default fp16x3 rc=$?"; tail -1 gpurun_out/bench_default_fp16x3.log | cut -c1-200
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub --dtype fp16x3 > gpurun_out/bench20_fp16x3.log 2>&1; echo "bench20 fp16x3 rc=$?"; tail -1 gpurun_out/bench20_fp16x3.log | cut -c1-200
+timeout 600 python bench.py --no-cpu-baseline --no-sub --dtype fp16x3m > gpurun_out/bench_default_fp16x3m.log 2>&1; echo "bench default fp16x3m rc=$?"; tail -1 gpurun_out/bench_default_fp16x3m.log | cut -c1-200
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub --dtype fp16x3m > gpurun_out/bench20_fp16x3m.log 2>&1; echo "bench20 fp16x3m rc=$?"; tail -1 gpurun_out/bench20_fp16x3m.log | cut -c1-200
 timeout 300 python bench.py --gpus 1 --force-gather --steps 2 --warmup 1 --no-cpu-baseline --no-sub > gpurun_out/bench_force_gather.log 2>&1; echo "bench force-gather rc=$?"; tail -1 gpurun_out/bench_force_gather.log | cut -c1-200
 timeout 600 python bench.py --gpus 1 --beam 5 --steps 32 --warmup 8 --no-cpu-baseline --no-sub > gpurun_out/bench_beam5.log 2>&1; echo "bench beam5 rc=$?"; tail -1 gpurun_out/bench_beam5.log | cut -c1-200
 for m in fp16x3 fp16x2; do
   timeout 600 tools/gemm_lab/lab 512 20 - $m > gpurun_out/r06_gemm_shapes_${m}_b512.txt 2>&1; echo "lab $m rc=$?"
 done
+timeout 600 python tools/extended_parity.py --ckpt 0 --batches 4 --first 3000 --out gpurun_out/r06_extended_parity_0_fp16x3_final.json 2>&1 | grep EXTENDED_PARITY | cut -c1-500
 timeout 600 python tools/tick_time.py 64,128,192,256,384,512,640 unfused,fused 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_tick_time.txt; echo "tick_time rc=$?"
 if [ -f tools/ab/libmolnextr_hip_stamps.so ]; then
   cp molnextr_amd/lib/libmolnextr_hip.so /tmp/mnx_cur.so

@@ -4,7 +4,7 @@
 cd /root/repo
 R=$GRAFT_REPO_ROOT
 EB=${EB:-512}
-DT=${DT:-fp16x3m}
+DT=${DT:-fp16x3}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
