@@ -98,7 +98,11 @@ class Scheme:
         ah, al = split(a, dt)
         wh, wl = split(ws, dt)
         main = ah @ wh.transpose(-1, -2)
-        if n in ("fp16x3", "bf16x3") and self.is_two(tag):
+        if n == "fp16x3+al8" and self.is_two(tag):      # the layers of `two`: third term al.wh on block-scaled e4m3 operands (FP8 rate)
+            corr = ah @ wl.transpose(-1, -2) + mx8(al) @ mx8(wh).transpose(-1, -2)
+        elif n == "fp16x3+al8":
+            corr = ah @ wl.transpose(-1, -2) + al @ wh.transpose(-1, -2)
+        elif n in ("fp16x3", "bf16x3") and self.is_two(tag):
             corr = ah @ wl.transpose(-1, -2)
         elif n in ("fp16x3", "bf16x3"):
             corr = ah @ wl.transpose(-1, -2) + al @ wh.transpose(-1, -2)
@@ -347,7 +351,7 @@ def main():
         return
     runs = [(name, ()) for name in args.schemes.split(",") if name]
     runs += [(name, tuple(t for t in two.split(",") if t)) for two in args.two for name in args.schemes.split(",")
-             if name in ("fp16x3", "bf16x3")]
+             if name in ("fp16x3", "bf16x3", "fp16x3+al8")]
     for name, two in runs:
         t0 = time.time()
         S = Scheme(name, two)
