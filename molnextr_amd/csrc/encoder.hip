@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ x,
-                                                          int S, int G) {
+                                                          int S, int G, int rpw) {
     constexpr int C = 8 * CPT;
     constexpr int PW = 128 * PE_NP;             // pixels per staged line
     constexpr int WS = C + 4;                   // weight row stride in LDS
@@ -47,13 +47,17 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
     float* wt = sm;             // [48][WS]
     float* pix = sm + 48 * WS;  // [3][4][PW]
     const int tid = threadIdx.x;
-    const int py = blockIdx.x, b = blockIdx.y;
+    const int b = blockIdx.y;
     const int p = tid >> 3, part = tid & 7;
     const int c0 = part * CPT;
     f32x4 wq[NWQ];
 #pragma unroll
     for (int k = 0; k < NWQ; ++k) wq[k] = ((const f32x4*)w_t)[min(tid + 256 * k, 12 * C - 1)];
-    for (int px0 = 0; px0 < G; px0 += 32 * PE_NP) {
+    // a workgroup takes `rpw` consecutive patch rows (round 6: two at G % 2 == 0 — the 24 KB of weights are staged once per
+    // workgroup, a quarter of what a patch row moves into the CU) in chunks of 96 patches; per output nothing changes
+    const int nchunk = (G + 32 * PE_NP - 1) / (32 * PE_NP);
+    for (int ch = 0; ch < rpw * nchunk; ++ch) {
+        const int py = blockIdx.x * rpw + ch / nchunk, px0 = (ch % nchunk) * 32 * PE_NP;
         f32x4 pq[NPQ];
 #pragma unroll
         for (int k = 0; k < NPQ; ++k) {
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < CPT / 4; ++j) bq[j] = *(const f32x4*)(bias + c0 + 4 * j);
         __builtin_amdgcn_sched_barrier(0);      // keep the requests together, ahead of the first wait
-        if (px0 > 0) __syncthreads();           // the previous chunk's pixels have been consumed
+        if (ch > 0) __syncthreads();            // the previous chunk's pixels have been consumed
         else {
 #pragma unroll
             for (int k = 0; k < NWQ; ++k) {
@@ -166,13 +170,14 @@ hipError_t launch_patch_embed(const float* img, const float* w_t, const float* b
                               const float* beta, float* x, int B, int S, int C, hipStream_t s) {
     if (C > 128 || (C & 31) || (S & 3) || S < 4) return hipErrorInvalidValue;
     const int G = S / 4;
-    dim3 grid(G, B), block(256);
+    const int rpw = (G % 2 == 0) ? 2 : 1;
+    dim3 grid(G / rpw, B), block(256);
     size_t smem = (size_t)(48 * (C + 4) + 3 * 4 * 128 * PE_NP) * sizeof(float);
     switch (C >> 3) {
-        case 4: hipLaunchKernelGGL(patch_embed_kernel<4>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
-        case 8: hipLaunchKernelGGL(patch_embed_kernel<8>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
-        case 12: hipLaunchKernelGGL(patch_embed_kernel<12>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
-        default: hipLaunchKernelGGL(patch_embed_kernel<16>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G); break;
+        case 4: hipLaunchKernelGGL(patch_embed_kernel<4>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G, rpw); break;
+        case 8: hipLaunchKernelGGL(patch_embed_kernel<8>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G, rpw); break;
+        case 12: hipLaunchKernelGGL(patch_embed_kernel<12>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G, rpw); break;
+        default: hipLaunchKernelGGL(patch_embed_kernel<16>, grid, block, smem, s, img, w_t, bias, gamma, beta, x, S, G, rpw); break;
     }
     return hipGetLastError();
 }

@@ -338,7 +338,9 @@ def test_patch_embed_isa_requests_its_staging_loads_together_and_has_a_branch_fr
     assert len(barriers) == 2
     taps = body[barriers[1]:body.index("global_store_dwordx4")]
     assert len(re.findall(r"s_cbranch", taps)) == 2, re.findall(r"s_cbranch\w*", taps)
-    assert len(re.findall(r"s_waitcnt vmcnt", taps)) <= 1
+    # (round 6: a workgroup walks two patch rows, so the chunk body is a real loop and the compiler keeps one more counted wait
+    #  behind the barrier for loads it hoisted across the iteration, next to the one for gamma / beta)
+    assert len(re.findall(r"s_waitcnt vmcnt", taps)) <= 2
     assert len(re.findall(r"v_pk_fma_f32", taps)) >= 96
     assert len(re.findall(r"ds_read_b128", taps)) >= 4 * 4 + 3          # a line: 4 taps x 4 weight quads, 3 pixel quads
 
