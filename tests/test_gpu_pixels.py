@@ -484,3 +484,29 @@ def test_two_term_tables_measured_on_both_checkpoints(gold, images, synth_ckpt, 
         assert r["flips"] == 0, (name, r)
         if name.startswith("fp16x3m"):
             assert r["logp_max_err"] < 5e-4 and r["logit_max_err"] < 5e-4, (name, r["logp_max_err"], r["logit_max_err"])
+
+
+def test_default_mode_on_images_beyond_the_fixtures_vs_the_oracle(synth_ckpt):
+    """The fixtures are 38 + 16 images; a gate met on them is a statement about them (fp16x3m met its 5e-4 gate on the fixtures
+    and reaches 8.7e-4 on further images: profiles/r06_extended_parity_*.json). So every run of the suite also asks the
+    from-pixels questions of images NO fixture holds, against the CPU oracle (bit-equal to the reference on every fixture): one
+    reference batch per checkpoint (32 images; 16 of the hostile one, whose rows all run to 480 tokens) in the DEFAULT operand mode — free-running rows exact, 0 argmax flips along the
+    oracle's ids, log-probs within 2e-4 and the raw logits of EVERY step within 5e-4 (measured 2.5e-4 over 192 images: half of
+    north_star's 1e-3 is the bound a default has to hold with room to spare)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import extended_parity as XP
+    from molnextr_amd.engine import DEFAULT_DTYPE, Engine
+    assert DEFAULT_DTYPE == "fp16x3"
+    recs = {}
+    for name, ck, first, rows in (("0", synth_ckpt, 5000, 32), ("stress", W.synthetic_checkpoint(1, stress=True), 6000, 16)):
+        eng = Engine(ck["encoder"], ck["decoder"], device=0, max_batch=32, dec_slots=64)
+        try:
+            r = XP.check(eng, ck, first, 1, rows=rows, verbose=False)
+        finally:
+            eng.close()
+        recs[name] = {k: v for k, v in r.items() if k != "batches"}
+        assert r["rows_exact_free_running"] == rows and r["flips"] == 0, (name, r)
+        assert r["logit_max_err_all_steps"] < 5e-4 and r["logp_max_err"] < 2e-4, (name, r["logit_max_err_all_steps"], r["logp_max_err"])
+        assert r["feature_max_err"] < 1e-4, (name, r["feature_max_err"])
+    _report("default_mode_beyond_fixtures", recs)
