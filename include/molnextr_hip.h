@@ -62,7 +62,8 @@ typedef enum {
  *                  Measured from pixels on both fixture checkpoints: every token / atom / bond still equal to the
  *                  reference's, 0 argmax flips in 12863 teacher-forced steps, log-probs within 1.8e-4, raw logits within
  *                  5.0e-4 (FP16X3: 2e-5 / 8e-5; north_star allows 1e-3); on 384 further images against the oracle the raw
- *                  logits reach 8.7e-4 (FP16X3: 2.0e-4), still 0 flips in 77790 steps — an OPT-IN throughput mode: the
+ *                  logits reach 8.7e-4, on 384 more of a hostile checkpoint 1.2e-3 (FP16X3: 2.4e-4), still 0 flips in 220 000
+ *                  steps — an OPT-IN throughput mode for callers who accept logits at north_star's edge: the
  *                  default stays FP16X3 (profiles/r06_two_term_tables_gpu.json, r06_extended_parity_*.json, DESIGN.md
  *                  section 4.3, tests/test_gpu_pixels.py).
  *                  Same weights, range and MNX_ERR_RANGE behaviour as FP16X3. mnx_set_op_terms changes the table. */

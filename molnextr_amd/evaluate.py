@@ -205,7 +205,8 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=4, help="per-GPU batch size; inference uses twice that")
     ap.add_argument("--dtype", default=None, choices=sorted(DTYPES),
                     help="encoder operand mode; default engine.DEFAULT_DTYPE = fp16x3 (every token / atom / bond as the reference's fp32 path; "
-                         "fp16x3m = qkv / fc1 / fc2 of Swin stage 3 on two product terms: faster, logits within 1e-3 without headroom)")
+                         "fp16x3m = qkv / fc1 / fc2 of Swin stage 3 on two product terms: faster, tokens exact on everything measured, raw logits up to "
+                         "1.2e-3 off on a hostile checkpoint)")
     ap.add_argument("--fp16", action="store_true",
                     help="the reference's flag (main.py:40, exps/eval.sh: fp16 autocast): without --dtype it selects the one-plane "
                          "fp16 operand mode, which stays closer to the fp32 result than the reference's autocast path does "

@@ -135,7 +135,8 @@ class molnextr:
     dtype: encoder operand mode. 'fp16x3' (the default, engine.DEFAULT_DTYPE: split fp16 operands, three MFMA terms per product:
     features equal the reference's to fp32 rounding level, logits within 2e-4), 'fp16x3m' (opt-in: the Linear layers of
     engine.FP16X3M_TWO_TERM on two terms, +8-11 % throughput; every token / atom / bond still the reference's on everything
-    measured, raw logits within 5e-4 on the fixtures and 8.7e-4 on further images — inside north_star's 1e-3 without headroom),
+    measured, raw logits within 5e-4 on the fixtures, 7.2e-4 on further images and up to 1.2e-3 on a hostile checkpoint — at and
+    beyond north_star's 1e-3),
     'bf16x3' (three terms with the fp32 exponent range), 'fp32' (exact-fp32 MFMA, slowest), 'bf16' / 'fp16' (fastest; argmax
     decisions near a tie can differ)."""
 
