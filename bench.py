@@ -391,7 +391,7 @@ def main():
     ap.add_argument("--max-len", type=int, default=480)
     ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["fp16x3", "fp16x3m", "bf16x3", "bf16", "fp16", "fp32"],
                     help="encoder operand mode. fp16x3 (default): three MFMA terms per product everywhere, fp32-class features (6e-6), "
-                         "raw logits within 2e-4 of the reference's at every step; fp16x3m (opt-in): the same with the Linear layers of "
+                         "raw logits within 2.5e-4 of the reference's at every step; fp16x3m (opt-in): the same with the Linear layers of "
                          "molnextr_amd.engine.FP16X3M_TWO_TERM (qkv / fc1 / fc2 of Swin stage 3) on two terms (activation lo plane "
                          "dropped): every token / atom / bond still the reference's on everything measured (0 flips in 90 000 "
                          "teacher-forced steps), raw logits within 5.0e-4 on the fixtures, 7.2e-4 on 256 further images and up to 1.2e-3 on 512 images of a hostile checkpoint (north_star: "

@@ -133,7 +133,7 @@ class molnextr:
     are meaningless as chemistry). There is no default: like the reference, the model cannot run without weights.
     device: torch.device('cuda', i) — an MI355X is required.
     dtype: encoder operand mode. 'fp16x3' (the default, engine.DEFAULT_DTYPE: split fp16 operands, three MFMA terms per product:
-    features equal the reference's to fp32 rounding level, logits within 2e-4), 'fp16x3m' (opt-in: the Linear layers of
+    features equal the reference's to fp32 rounding level, logits within 2.5e-4), 'fp16x3m' (opt-in: the Linear layers of
     engine.FP16X3M_TWO_TERM on two terms, +8-11 % throughput; every token / atom / bond still the reference's on everything
     measured, raw logits within 5e-4 on the fixtures, 7.2e-4 on further images and up to 1.2e-3 on a hostile checkpoint — at and
     beyond north_star's 1e-3),
